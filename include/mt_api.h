@@ -1,0 +1,185 @@
+/*
+ * mt_api.h -- C ABI of libmt_hip.so, the MI355X (gfx950) native op library that sits
+ * under the GAN+VAE training step of AdaINModel / BaseModel.
+ *
+ * The reference (kartikkadur/MasterThesis) has no FFI of its own: every arithmetic op on
+ * its hot path is an implicit torch.nn call.  Each entry
+ * point below replaces one of those call sites; the reference site is cited per group.
+ *
+ * Conventions
+ *  - Activations are NHWC, channels padded to a multiple of 8 ("Cp"); pad channels hold
+ *    zeros and every kernel preserves that.  dtype is MT_F32 or MT_BF16 (storage type of
+ *    activations; all accumulation, statistics and losses are fp32).
+ *  - Parameters stay in the reference's layouts (OIHW fp32 for Conv2d, IOHW for
+ *    ConvTranspose2d, [out,in] for Linear) so checkpoints interchange; the library packs
+ *    them into MFMA-friendly tiles with mt_conv_pack().
+ *  - Ownership: the caller (PyTorch) allocates every buffer and workspace; the library
+ *    borrows pointers for the duration of a call and never allocates or frees.
+ *  - Every call takes the HIP stream explicitly; no global state, re-entrant.
+ *  - Return value: 0 on success, non-zero on error; mt_last_error() gives a thread-local
+ *    message.  No C++ exception crosses the ABI.
+ */
+#ifndef MT_API_H
+#define MT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mt_stream_t; /* hipStream_t */
+
+enum { MT_F32 = 0, MT_BF16 = 1 };
+enum { MT_PAD_ZERO = 0, MT_PAD_REFLECT = 1 };
+enum { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU = 2, MT_ACT_TANH = 3 };
+/* which packed copy of a weight tensor */
+enum { MT_PACK_FWD = 0, MT_PACK_BWD_DATA = 1 };
+enum { MT_NORM_INSTANCE = 0, MT_NORM_ADAIN = 1, MT_NORM_LAYER = 2 };
+
+/* Convolution problem: nn.Conv2d (blocks.py:33-35) preceded by nn.ReflectionPad2d
+ * (functions.py:51) when pad_mode == MT_PAD_REFLECT, or nn.ConvTranspose2d (blocks.py:73)
+ * when transposed != 0.  H, W, Ci describe the op's INPUT, Co its output (logical channel
+ * counts; buffers use the padded counts). */
+typedef struct mt_conv_desc {
+  int dtype;
+  int transposed; /* 0: Conv2d, 1: ConvTranspose2d */
+  int N, H, W;
+  int Ci, Co;
+  int kh, kw;
+  int stride;
+  int pad;
+  int pad_mode;   /* Conv2d only */
+  int out_pad;    /* ConvTranspose2d only */
+  int act;        /* fused epilogue activation of the forward */
+  float slope;    /* LeakyReLU slope */
+} mt_conv_desc;
+
+const char* mt_last_error(void);
+int mt_version(void);
+static inline int mt_padc(int c) { return (c + 7) & ~7; }
+
+/* ---- convolution family (K1-K8, K12, K17): blocks.py:10-91, networks.py ------------- */
+int mt_conv_out_hw(const mt_conv_desc* d, int* Ho, int* Wo);
+size_t mt_conv_pack_bytes(const mt_conv_desc* d, int which);
+/* w: reference-layout fp32 weights.  pack: mt_conv_pack_bytes() bytes. */
+int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, mt_stream_t s);
+/* y = act(conv(x) + bias).  bias may be NULL (length Co, fp32). */
+int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
+                void* y, mt_stream_t s);
+size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d);
+/* dx = conv_bwd_data(dy).  dy is the gradient w.r.t. the pre-activation output. */
+int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx,
+                     void* ws, size_t ws_bytes, mt_stream_t s);
+size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
+/* dw (reference layout, fp32, overwritten), dbias (fp32 [Co], overwritten; may be NULL). */
+int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw,
+                       float* dbias, void* ws, size_t ws_bytes, mt_stream_t s);
+
+/* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
+int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,
+                  int out, int act, mt_stream_t s);
+int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                  float* db, int n, int in, int out, mt_stream_t s);
+
+/* ---- normalisation family (K9, K10, K11): functions.py:17, norm.py:5-33 -------------- */
+/* sums[n][c] = {sum x, sum x^2} over H*W (fp32, [N][Cp][2]); overwritten. */
+int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);
+/* scale/shift [N][Cp] for y = act(scale*x + shift); mean/rstd saved for backward.
+ * mode INSTANCE: gamma=beta=NULL.  ADAIN: gb = fc(s) [N][2*C] (weight = 1+gb[:, :C], bias =
+ * gb[:, C:]).  LAYER: per-sample statistics over (C,H,W); gamma,beta [C] (norm.py:16-21). */
+int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* gamma,
+                     const float* beta, float* scale, float* shift, float* mean, float* rstd,
+                     int N, int HW, int C, int Cp, float eps, mt_stream_t s);
+/* y = act(scale[n][c]*x + shift[n][c]) (+ res).  res may be NULL. */
+int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
+                       const void* res, void* y, int N, int HW, int Cp, int act, float slope,
+                       mt_stream_t s);
+/* g = dy * act'(scale*x+shift); sums2[n][c] = {sum g, sum g*x}. */
+int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale,
+                    const float* shift, float* sums2, int N, int HW, int Cp, int act,
+                    float slope, mt_stream_t s);
+/* coefficients for dx = c1*g + c2 + c3*x; plus parameter gradients:
+ * ADAIN: dgb [N][2C]; LAYER: dgamma, dbeta [C]. */
+int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const float* rstd,
+                         const float* gb, const float* gamma, float* c1, float* c2, float* c3,
+                         float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,
+                         mt_stream_t s);
+int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
+                      const float* shift, const float* c1, const float* c2, const float* c3,
+                      void* dx, int N, int HW, int Cp, int act, float slope, mt_stream_t s);
+
+/* ---- elementwise / pooling / layout (K13, K14, K15, K19) ----------------------------- */
+int mt_act_fwd(int dtype, const void* x, void* y, size_t n, int act, float slope, mt_stream_t s);
+/* dx = dy * act'(.) evaluated from the activation OUTPUT y. */
+int mt_act_bwd(int dtype, const void* dy, const void* y, void* dx, size_t n, int act,
+               float slope, mt_stream_t s);
+int mt_add(int dtype, const void* a, const void* b, void* y, size_t n, mt_stream_t s);
+/* y = x + noise (misc.py:22-26).  noise given (parity mode) ... */
+/* ... or generated on device: Philox4x32-10 + Box-Muller, N(0,1), counter = element index. */
+int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t seed,
+                          uint64_t offset, mt_stream_t s);
+int mt_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
+int mt_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
+/* AvgPool2d(3, stride 2, pad 1, count_include_pad=False) (networks.py:447) */
+int mt_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
+int mt_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
+/* AdaptiveAvgPool2d(1): y fp32 [N][C] (logical channels). */
+int mt_gap_fwd(int dtype, const void* x, float* y, int N, int HW, int C, int Cp, mt_stream_t s);
+int mt_gap_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, int Cp, mt_stream_t s);
+/* generic strided (element strides sn,sc,sh,sw) source of dtype src_dtype -> canonical NHWC
+ * padded tensor of dtype dst_dtype, pad channels zeroed. */
+int mt_to_nhwc(int src_dtype, const void* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+               int dst_dtype, void* y, int N, int C, int H, int W, mt_stream_t s);
+/* canonical NHWC padded -> dense NCHW fp32 (logical channels). */
+int mt_to_nchw_f32(int dtype, const void* x, float* y, int N, int C, int H, int W, mt_stream_t s);
+/* Style-encoder input (networks.py:138-140): out[...,0:C]=img, out[...,C:C+D]=onehot[n]. */
+int mt_cat_class_planes(int dtype, const void* img, const float* cls, void* out, int N, int HW,
+                        int C, int D, mt_stream_t s);
+/* backward of the above for the image part: dimg[..., 0:C] = dout[..., 0:C]. */
+int mt_slice_channels(int dtype, const void* x, void* y, int N, int HW, int Cx, int C,
+                      mt_stream_t s);
+
+/* ---- losses (K16, K18): loss.py:52-64, adain_model.py:74,303-314,379-381,396-399 ------ */
+/* mean BCE-with-logits of x (NHWC padded, logical C) against a constant target t in {0,1}.
+ * loss: fp32 scalar (overwritten). */
+int mt_bce_const_fwd(int dtype, const void* x, float t, float* loss, size_t npix, int C, int Cp,
+                     mt_stream_t s);
+/* dx = gscale[0] * (sigmoid(x) - t) / (npix*C) on logical channels, 0 on pad. */
+int mt_bce_const_bwd(int dtype, const void* x, float t, const float* gscale, void* dx,
+                     size_t npix, int C, int Cp, mt_stream_t s);
+/* mean BCE-with-logits of fp32 x[n] against fp32 targets t[n]. */
+int mt_bce_target_fwd(const float* x, const float* t, float* loss, size_t n, mt_stream_t s);
+int mt_bce_target_bwd(const float* x, const float* t, const float* gscale, float* dx, size_t n,
+                      mt_stream_t s);
+/* mean |a-b| over `count` logical elements (n = padded element count). */
+int mt_l1_fwd(int dtype, const void* a, const void* b, float* loss, size_t n, size_t count,
+              mt_stream_t s);
+/* da = gscale * sign(a-b)/count ; db = -da (either may be NULL). */
+int mt_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, void* db,
+              size_t n, size_t count, mt_stream_t s);
+/* mean x^2 over count logical elements (adain_model.py:396-399). */
+int mt_l2mean_fwd(int dtype, const void* x, float* loss, size_t n, size_t count, mt_stream_t s);
+int mt_l2mean_bwd(int dtype, const void* x, const float* gscale, void* dx, size_t n, size_t count,
+                  mt_stream_t s);
+/* z = eps*exp(0.5*logvar)+mu (networks.py:130-135). */
+int mt_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n,
+                   mt_stream_t s);
+int mt_reparam_bwd(const float* logvar, const float* eps, const float* dz, float* dmu,
+                   float* dlogvar, size_t n, mt_stream_t s);
+/* kl = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) (adain_model.py:313-314; a SUM). */
+int mt_kl_fwd(const float* mu, const float* logvar, float* kl, size_t n, mt_stream_t s);
+int mt_kl_bwd(const float* mu, const float* logvar, const float* gscale, float* dmu,
+              float* dlogvar, size_t n, mt_stream_t s);
+
+/* ---- optimizer (K20): torch.optim.Adam, adain_model.py:57-61 -------------------------- */
+/* One fused launch over `count` tensors.  ptrs: device array of 4*count pointers laid out
+ * [p0,g0,m0,v0,p1,...]; sizes: device array of element counts; L2-coupled weight decay. */
+int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float lr,
+                  float beta1, float beta2, float eps, float wd, int step, mt_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MT_API_H */

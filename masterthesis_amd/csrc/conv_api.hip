@@ -1,0 +1,256 @@
+// Host side of the convolution family: turns an mt_conv_desc into gather-GEMM launches.
+//  - Conv2d forward: one gather-GEMM, reflection folded into the gather (no padded copy).
+//  - Conv2d data gradient / ConvTranspose2d forward: stride^2 sub-pixel phases, each a
+//    stride-1 gather-GEMM over the taps of matching parity writing a strided output grid;
+//    for reflect padding the phases write the gradient of the padded map into the
+//    workspace and reflect_fold adds the border back (adjoint of ReflectionPad2d).
+//  - weight gradients: wgrad kernel into an fp32 [row][tap][col] workspace, then unpack to
+//    the reference layout (OIHW / IOHW).
+// Reference call sites: blocks.py:29-35 (pad+Conv2d), blocks.py:73 (ConvTranspose2d).
+#include "mt_common.h"
+#include "conv_params.h"
+#include <string.h>
+
+static inline int esz(int dtype) { return dtype == MT_BF16 ? 2 : 4; }
+static inline int vec(int dtype) { return 16 / esz(dtype); }
+static inline int posmod(int a, int m) { return ((a % m) + m) % m; }
+
+static int check_desc(const mt_conv_desc* d) {
+  MT_CHECK(d != nullptr, "conv: null descriptor");
+  MT_CHECK(d->dtype == MT_F32 || d->dtype == MT_BF16, "conv: bad dtype %d", d->dtype);
+  MT_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0, "conv: bad shape");
+  MT_CHECK(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= MT_MAX_TAPS, "conv: %dx%d filter unsupported", d->kh, d->kw);
+  MT_CHECK(d->stride >= 1 && d->stride <= 4, "conv: stride %d unsupported", d->stride);
+  MT_CHECK(d->pad >= 0, "conv: negative padding");
+  if (!d->transposed && d->pad_mode == MT_PAD_REFLECT)
+    MT_CHECK(d->pad < d->H && d->pad < d->W, "conv: reflect pad %d >= input size", d->pad);
+  if (d->transposed) MT_CHECK(d->pad_mode == MT_PAD_ZERO, "convT: reflect padding unsupported");
+  int Ho, Wo;
+  if (d->transposed) {
+    Ho = (d->H - 1) * d->stride - 2 * d->pad + d->kh + d->out_pad;
+    Wo = (d->W - 1) * d->stride - 2 * d->pad + d->kw + d->out_pad;
+  } else {
+    Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    MT_CHECK(d->H + 2 * d->pad >= d->kh && d->W + 2 * d->pad >= d->kw, "conv: filter larger than padded input");
+  }
+  MT_CHECK(Ho > 0 && Wo > 0, "conv: empty output");
+  return 0;
+}
+
+extern "C" int mt_conv_out_hw(const mt_conv_desc* d, int* Ho, int* Wo) {
+  if (check_desc(d)) return 1;
+  if (d->transposed) {
+    *Ho = (d->H - 1) * d->stride - 2 * d->pad + d->kh + d->out_pad;
+    *Wo = (d->W - 1) * d->stride - 2 * d->pad + d->kw + d->out_pad;
+  } else {
+    *Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    *Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+  }
+  return 0;
+}
+
+// Does `which` use the phase-decomposed ("scatter form") pack?
+static inline bool phased(const mt_conv_desc* d, int which) {
+  return d->transposed ? (which == MT_PACK_FWD) : (which == MT_PACK_BWD_DATA);
+}
+
+extern "C" size_t mt_conv_pack_bytes(const mt_conv_desc* d, int which) {
+  (void)which;
+  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * esz(d->dtype);
+}
+
+// taps of phase (ph, pw) in (kh, kw) order
+static int phase_taps(const mt_conv_desc* d, int ph, int pw, short* kh, short* kw) {
+  int n = 0;
+  for (int a = 0; a < d->kh; a++)
+    for (int b = 0; b < d->kw; b++)
+      if (a % d->stride == ph && b % d->stride == pw) { kh[n] = (short)a; kw[n] = (short)b; n++; }
+  return n;
+}
+
+extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  const int K2 = d->kh * d->kw;
+  PackParams p;
+  memset(&p, 0, sizeof(p));
+  p.kW = d->kw;
+  // which tensor dimension is the GEMM row (output channel of the launch) / column
+  long s_ci, s_co;  // element strides of ci / co in the reference layout
+  if (d->transposed) { s_ci = (long)d->Co * K2; s_co = K2; }   // [Ci][Co][kh][kw]
+  else { s_co = (long)d->Ci * K2; s_ci = K2; }                 // [Co][Ci][kh][kw]
+  const bool rows_are_co = d->transposed ? (which == MT_PACK_FWD) : (which == MT_PACK_FWD);
+  if (rows_are_co) { p.R = d->Co; p.C = d->Ci; p.sr = s_co; p.sc = s_ci; }
+  else { p.R = d->Ci; p.C = d->Co; p.sr = s_ci; p.sc = s_co; }
+  p.Rp = mt_padc(p.R);
+  p.Cp = mt_padc(p.C);
+  if (!phased(d, which)) {
+    p.ntaps = K2;
+    for (int a = 0; a < d->kh; a++)
+      for (int b = 0; b < d->kw; b++) { p.kh[a * d->kw + b] = (short)a; p.kw[a * d->kw + b] = (short)b; }
+    return mt_launch_pack(d->dtype, w, pack, p, s);
+  }
+  char* out = (char*)pack;
+  for (int ph = 0; ph < d->stride; ph++)
+    for (int pw = 0; pw < d->stride; pw++) {
+      p.ntaps = phase_taps(d, ph, pw, p.kh, p.kw);
+      if (p.ntaps == 0) continue;
+      if (mt_launch_pack(d->dtype, w, out, p, s)) return 2;
+      out += (size_t)p.Rp * p.ntaps * p.Cp * esz(d->dtype);
+    }
+  return 0;
+}
+
+// scatter-form launches shared by Conv2d bwd_data and ConvTranspose2d fwd.
+//   out[o] = sum_k in[(o + e - k)/stride] * W[k]   over k with (o + e - k) % stride == 0
+// in: [N][Hin][Win][Cin_p], out: [N][Hd][Wd][Cout_p]
+static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
+                        const float* bias, int nbias, void* out, int Hd, int Wd, int Cout_p, int e, int act,
+                        hipStream_t s) {
+  const int sz = esz(d->dtype), V = vec(d->dtype), st = d->stride;
+  const char* wp = (const char*)pack;
+  for (int ph = 0; ph < st; ph++)
+    for (int pw = 0; pw < st; pw++) {
+      short kh[MT_MAX_TAPS], kw[MT_MAX_TAPS];
+      const int nt = phase_taps(d, ph, pw, kh, kw);
+      const int o0h = posmod(ph - e, st), o0w = posmod(pw - e, st);
+      const int Hg = o0h < Hd ? (Hd - o0h + st - 1) / st : 0;
+      const int Wg = o0w < Wd ? (Wd - o0w + st - 1) / st : 0;
+      IgemmParams p;
+      memset(&p, 0, sizeof(p));
+      p.x = (const char*)in; p.w = wp; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
+      p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
+      p.Ho = Hg; p.Wo = Wg; p.M = d->N * Hg * Wg;
+      p.Co = Cout_p; p.CoRows = Cout_p;
+      p.Hout = Hd; p.Wout = Wd; p.os = st; p.oh0 = o0h; p.ow0 = o0w; p.is = 1;
+      p.ntaps = nt; p.cpc = Cin_p / V; p.nchunks = nt * p.cpc;
+      p.pad_mode = MT_PAD_ZERO; p.act = act; p.slope = d->slope;
+      for (int t = 0; t < nt; t++) {
+        p.dh[t] = (short)((o0h + e - kh[t]) / st);
+        p.dw[t] = (short)((o0w + e - kw[t]) / st);
+      }
+      if (p.M > 0 && mt_launch_igemm(d->dtype, p, s)) return 2;
+      wp += (size_t)Cout_p * nt * Cin_p * sz;
+    }
+  return 0;
+}
+
+// gather-form launch shared by Conv2d fwd and ConvTranspose2d bwd_data.
+//   out[o] = sum_k in[o*stride - pad + k] * W[k]
+static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
+                       const float* bias, int nbias, void* out, int Hg, int Wg, int Cout_p, int pad_mode, int act,
+                       hipStream_t s) {
+  const int sz = esz(d->dtype), V = vec(d->dtype);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)in; p.w = (const char*)pack; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
+  p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
+  p.Ho = Hg; p.Wo = Wg; p.M = d->N * Hg * Wg;
+  p.Co = Cout_p; p.CoRows = Cout_p;
+  p.Hout = Hg; p.Wout = Wg; p.os = 1; p.oh0 = 0; p.ow0 = 0; p.is = d->stride;
+  p.ntaps = d->kh * d->kw; p.cpc = Cin_p / V; p.nchunks = p.ntaps * p.cpc;
+  p.pad_mode = pad_mode; p.act = act; p.slope = d->slope;
+  for (int a = 0; a < d->kh; a++)
+    for (int b = 0; b < d->kw; b++) {
+      p.dh[a * d->kw + b] = (short)(a - d->pad);
+      p.dw[a * d->kw + b] = (short)(b - d->pad);
+    }
+  return mt_launch_igemm(d->dtype, p, s);
+}
+
+extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
+                           mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  if (!d->transposed)
+    return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s);
+  return scatter_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad, d->act, s);
+}
+
+extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {
+  if (d->transposed || d->pad_mode != MT_PAD_REFLECT || d->pad == 0) return 0;
+  return (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * mt_padc(d->Ci) * esz(d->dtype);
+}
+
+extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, void* ws,
+                                size_t ws_bytes, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  if (d->transposed)
+    return gather_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, MT_PAD_ZERO, MT_ACT_NONE, s);
+  const int P = (d->pad_mode == MT_PAD_REFLECT) ? d->pad : 0;
+  if (P == 0)
+    return scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, d->pad, MT_ACT_NONE, s);
+  MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_data_ws_bytes(d), "conv_bwd_data: workspace too small");
+  if (scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s))
+    return 2;
+  return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
+}
+
+extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
+  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+}
+
+extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                  void* ws, size_t ws_bytes, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_weight_ws_bytes(d), "conv_bwd_weight: workspace too small");
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  const int sz = esz(d->dtype), V = vec(d->dtype);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  PackParams u;
+  memset(&u, 0, sizeof(u));
+  p.out = (float*)ws;
+  p.N = d->N; p.is = d->stride; p.ntaps = K2;
+  u.kW = d->kw; u.ntaps = K2;
+  for (int a = 0; a < d->kh; a++)
+    for (int b = 0; b < d->kw; b++) {
+      const int t = a * d->kw + b;
+      p.dh[t] = (short)(a - d->pad); p.dw[t] = (short)(b - d->pad);
+      u.kh[t] = (short)a; u.kw[t] = (short)b;
+    }
+  if (!d->transposed) {
+    // dW[co][kh][kw][ci] = sum dy[n,ho,wo,co] * x[n, pad(ho*s-p+kh), pad(wo*s-p+kw), ci]
+    p.a = (const char*)dy; p.Cab = Cop * sz; p.CaRows = Cop; p.Ho = Ho; p.Wo = Wo;
+    p.b = (const char*)x; p.Hi = d->H; p.Wi = d->W; p.Cbb = Cip * sz; p.cpc = Cip / V;
+    p.pad_mode = d->pad_mode;
+    u.R = d->Co; u.C = d->Ci; u.Cp = Cip; u.sr = (long)d->Ci * K2; u.sc = K2;
+  } else {
+    // dW[ci][co][kh][kw] = sum x[n,hi,wi,ci] * dy[n, hi*s-p+kh, wi*s-p+kw, co]  (zero outside)
+    p.a = (const char*)x; p.Cab = Cip * sz; p.CaRows = Cip; p.Ho = d->H; p.Wo = d->W;
+    p.b = (const char*)dy; p.Hi = Ho; p.Wi = Wo; p.Cbb = Cop * sz; p.cpc = Cop / V;
+    p.pad_mode = MT_PAD_ZERO;
+    u.R = d->Ci; u.C = d->Co; u.Cp = Cop; u.sr = (long)d->Co * K2; u.sc = K2;
+  }
+  p.M = d->N * p.Ho * p.Wo;
+  p.nchunks = p.ntaps * p.cpc;
+  const int ncols = p.nchunks * V;
+  const int tiles = cdiv(p.CaRows, 128) * cdiv(ncols, 128);
+  int nsplit = cdiv(768, tiles);
+  const int maxsplit = cdiv(p.M, 256);
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  p.mchunk = cdiv(cdiv(p.M, nsplit), 64) * 64;
+  nsplit = cdiv(p.M, p.mchunk);
+  if (hipMemsetAsync(ws, 0, (size_t)p.CaRows * ncols * sizeof(float), s) != hipSuccess) {
+    mt_set_error("conv_bwd_weight: memset failed");
+    return 2;
+  }
+  if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
+  if (mt_launch_unpack((const float*)ws, dw, u, s)) return 2;
+  if (dbias != nullptr) {
+    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, s)) return 2;
+  }
+  return 0;
+}

@@ -1,0 +1,584 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X): forward / data-gradient /
+// transposed-conv share one gather-GEMM kernel (igemm_kernel); the weight gradient is a
+// second kernel that reduces over pixels (wgrad_kernel).  NHWC activations with channel
+// counts padded to 8, so every 16-byte chunk of the reduction dimension lies inside one
+// filter tap.  MFMA: v_mfma_f32_16x16x32_bf16 (bf16 storage) or v_mfma_f32_16x16x4_f32
+// (exact fp32 parity path), fp32 accumulation in both.
+//
+// Replaces: nn.ReflectionPad2d + nn.Conv2d (reference blocks.py:29-35), nn.ConvTranspose2d
+// (blocks.py:73) and their autograd backward.
+#include "mt_common.h"
+#include "conv_params.h"
+
+// ------------------------------------------------------------------------------------------
+// gather-GEMM:  Y[co][pixel] = sum_{tap, ci} Wp[co][tap][ci] * X[n, f(ho)+dh(tap), f(wo)+dw(tap), ci]
+// The weight tile is the MFMA A operand (rows = output channels) and the gathered pixel
+// tile the B operand, so each lane ends up with 4 consecutive output channels of one pixel
+// (a packed 8/16-byte NHWC store).
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (BF16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]),
+                                                 acc, 0, 0, 0);
+  }
+}
+
+// bijective XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+// contiguous range of tiles so neighbouring pixel tiles (shared halo rows) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+template <bool BF16, int WT>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int PT = 128;                       // pixels per block tile
+  constexpr int WC = (WT >= 64) ? 64 : WT;      // wave tile: output channels
+  constexpr int WP = (WT == 128) ? 64 : 32;     // wave tile: pixels
+  constexpr int NWP = PT / WP;                  // waves along the pixel dimension
+  constexpr int FC = WC / 16, FP = WP / 16;
+  constexpr int SZ = BF16 ? 2 : 4;
+  constexpr int WLD = (WT * 8 + 255) / 256;     // weight chunks staged per thread per k-step
+
+  __shared__ u32x4 sW[2][WT * 8];
+  __shared__ u32x4 sX[2][PT * 8];
+  __shared__ int sTap[64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int wcI = wv / NWP, wpI = wv % NWP;
+
+  if (tid < 64) sTap[tid] = tid < p.ntaps ? (((int)p.dh[tid] << 16) | ((int)p.dw[tid] & 0xffff)) : 0;
+
+  const int nWT = (p.CoRows + WT - 1) / WT;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wt = wg % nWT, pt = wg / nWT;
+
+  // ---- per-thread staging coordinates (fixed over the k loop) ----
+  const int c = tid & 7, r0 = tid >> 3;
+  const int HoWo = p.Ho * p.Wo;
+  int hb[4], wb[4];
+  size_t ib[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = pt * PT + r0 + 32 * i;
+    rv[i] = m < p.M;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HoWo;
+    const int rem = mm - n * HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    hb[i] = ho * p.is;
+    wb[i] = wo * p.is;
+    ib[i] = (size_t)n * p.Hi * p.Wi * p.Cib;
+  }
+  int q = c;
+  int tap = q / p.cpc;
+  int cq = q - tap * p.cpc;
+  const int step_t = 8 / p.cpc, step_r = 8 % p.cpc;
+
+  u32x4 xr[4], wr[WLD];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int rl = r0 + 32 * i;
+      const int row = wt * WT + rl;
+      const bool ok = (rl < WT) && (row < p.CoRows) && (q < p.nchunks);
+      wr[i] = ok ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)row * p.nchunks + q) * 16) : zero4;
+    }
+    if (tap < p.ntaps) {
+      const int t = sTap[tap];
+      const int dh = t >> 16, dw = (int)(short)(t & 0xffff);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int hi = hb[i] + dh, wi = wb[i] + dw;
+        bool ok = rv[i];
+        if (p.pad_mode == MT_PAD_REFLECT) {
+          hi = hi < 0 ? -hi : hi;
+          hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
+          wi = wi < 0 ? -wi : wi;
+          wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
+        } else {
+          ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+        }
+        const size_t off = ib[i] + ((size_t)hi * p.Wi + wi) * p.Cib + (size_t)cq * 16;
+        xr[i] = ok ? *reinterpret_cast<const u32x4*>(p.x + off) : zero4;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) xr[i] = zero4;
+    }
+    q += 8;
+    tap += step_t;
+    cq += step_r;
+    if (cq >= p.cpc) { cq -= p.cpc; tap++; }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int rl = r0 + 32 * i;
+      if (rl < WT) sW[buf][rl * 8 + (c ^ (rl & 7))] = wr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int rl = r0 + 32 * i;
+      sX[buf][rl * 8 + (c ^ (rl & 7))] = xr[i];
+    }
+  };
+
+  f32x4 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; a++)
+#pragma unroll
+    for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.nchunks + 7) >> 3;
+  __syncthreads();  // sTap visible
+  if (nk > 0) { gload(); lstore(0); }
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ks++) {
+    const int cur = ks & 1;
+    const bool more = (ks + 1) < nk;
+    if (more) gload();  // global loads for the next k-step fly under this step's MFMAs
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+      u32x4 wf[FC], xf[FP];
+#pragma unroll
+      for (int a = 0; a < FC; a++) {
+        const int row = wcI * WC + a * 16 + fr;
+        wf[a] = sW[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
+      }
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        const int row = wpI * WP + b * 16 + fr;
+        xf[b] = sX[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
+      }
+#pragma unroll
+      for (int a = 0; a < FC; a++)
+#pragma unroll
+        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation, packed NHWC store (4 consecutive channels per lane) ----
+#pragma unroll
+  for (int b = 0; b < FP; b++) {
+    const int m = pt * PT + wpI * WP + b * 16 + fr;
+    if (m >= p.M) continue;
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    const int oh = ho * p.os + p.oh0, ow = wo * p.os + p.ow0;
+    if ((unsigned)oh >= (unsigned)p.Hout || (unsigned)ow >= (unsigned)p.Wout) continue;
+    char* yp = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
+#pragma unroll
+    for (int a = 0; a < FC; a++) {
+      const int co = wt * WT + wcI * WC + a * 16 + fg * 4;
+      if (co >= p.Co) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t = acc[a][b][j];
+        if (p.bias != nullptr && (co + j) < p.nbias) t += p.bias[co + j];
+        v[j] = act_apply(t, p.act, p.slope);
+      }
+      if constexpr (BF16) {
+        u32x2 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(yp + (size_t)co * 2) = o;
+      } else {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(yp + (size_t)co * 4) = o;
+      }
+    }
+  }
+}
+
+template <bool BF16>
+static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
+  const int nPT = cdiv(p.M, 128);
+  if (p.M <= 0) return 0;
+  if (p.CoRows > 64) {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 128>), dim3(nPT * cdiv(p.CoRows, 128)), dim3(256), 0, s, p);
+  } else if (p.CoRows > 32) {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 64>), dim3(nPT), dim3(256), 0, s, p);
+  } else if (p.CoRows > 16) {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 32>), dim3(nPT), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 16>), dim3(nPT), dim3(256), 0, s, p);
+  }
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
+  MT_CHECK(p.ntaps <= 64, "igemm: %d taps > 64", p.ntaps);
+  MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
+  return dtype == MT_BF16 ? launch_igemm_t<true>(p, s) : launch_igemm_t<false>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient:  out[ca][tap][cb] += sum_pixels A[pixel][ca] * B[n, f(ho)+dh, f(wo)+dw, cb]
+// Both operands are pixel-major in memory, i.e. the reduction index is the slow one, so
+// the bf16 path reads MFMA fragments with the hardware transposing LDS read
+// ds_read_b64_tr_b16; the fp32 path needs one element per lane and uses ds_read_b32.
+// Split over pixel ranges (blockIdx.y) with fp32 atomic accumulation into `out`.
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int KP = BF16 ? 64 : 32;       // pixels per k-step
+  constexpr int V = BF16 ? 8 : 4;          // elements per 16-byte chunk
+  constexpr int CPR = 128 / V;             // chunks per 128-element tile row (16 / 32)
+  constexpr int RPT = 256 / CPR;           // tile rows covered by one pass of the block (16 / 8)
+  constexpr int NLD = KP / RPT;            // chunks per thread per tile (4)
+  constexpr int ROWB = 128 * (BF16 ? 2 : 4);  // LDS row bytes (256 / 512)
+
+  __shared__ u32x4 sA[2][KP * CPR];
+  __shared__ u32x4 sB[2][KP * CPR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int waI = wv >> 1, wbI = wv & 1;   // wave tile: 64 a-channels x 64 columns
+
+  const int nAT = (p.CaRows + 127) / 128;
+  const int at = blockIdx.x % nAT, bt = blockIdx.x / nAT;
+  const int mbeg = blockIdx.y * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  if (mbeg >= mend) return;
+
+  // staging coordinates
+  const int cc = tid % CPR, rr = tid / CPR;
+  // A: channel chunk
+  const int a_ch0 = at * 128 + cc * V;
+  const bool a_ok = a_ch0 < p.CaRows;
+  // B: column chunk -> (tap, channel chunk)
+  const int qb = bt * CPR + cc;
+  const bool b_ok = qb < p.nchunks;
+  int btap = 0, bcq = 0, bdh = 0, bdw = 0;
+  if (b_ok) {
+    btap = qb / p.cpc;
+    bcq = qb - btap * p.cpc;
+    bdh = p.dh[btap];
+    bdw = p.dw[btap];
+  }
+  // pixel coordinates of the NLD rows this thread stages, advanced by KP every step
+  int pn[NLD], pho[NLD], pwo[NLD];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < NLD; i++) {
+    const int m = mbeg + rr + RPT * i;
+    pn[i] = m / HoWo;
+    const int rem = m - pn[i] * HoWo;
+    pho[i] = rem / p.Wo;
+    pwo[i] = rem - pho[i] * p.Wo;
+  }
+  const int adv_h = KP / p.Wo, adv_w = KP % p.Wo;
+
+  u32x4 ar[NLD], br[NLD];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  int mrow = mbeg + rr;  // pixel index of row i=0 for the next load
+
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int m = mrow + RPT * i;
+      const bool pv = m < mend;
+      ar[i] = (pv && a_ok) ? *reinterpret_cast<const u32x4*>(p.a + (size_t)m * p.Cab + (size_t)a_ch0 * (16 / V))
+                           : zero4;
+      bool ok = pv && b_ok;
+      int hi = pho[i] * p.is + bdh, wi = pwo[i] * p.is + bdw;
+      if (p.pad_mode == MT_PAD_REFLECT) {
+        hi = hi < 0 ? -hi : hi;
+        hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
+        wi = wi < 0 ? -wi : wi;
+        wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
+      } else {
+        ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+      }
+      const size_t off = (((size_t)pn[i] * p.Hi + hi) * p.Wi + wi) * p.Cbb + (size_t)bcq * 16;
+      br[i] = ok ? *reinterpret_cast<const u32x4*>(p.b + off) : zero4;
+      // advance this row's pixel by KP
+      pwo[i] += adv_w;
+      pho[i] += adv_h;
+      if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; pho[i]++; }
+      while (pho[i] >= p.Ho) { pho[i] -= p.Ho; pn[i]++; }
+    }
+    mrow += KP;
+  };
+  // LDS image: row = pixel, swizzled so that the transposing / strided fragment reads are
+  // bank-conflict free (bf16: 32-byte slots XOR key(row); fp32: 64-byte slots XOR row&7).
+  auto swz = [&](int prow, int c16) -> int {
+    if constexpr (BF16) {
+      const int key = (prow & 3) | ((prow >> 1) & 4);
+      return prow * CPR + (c16 ^ (key << 1));
+    } else {
+      return prow * CPR + (c16 ^ ((prow & 7) << 2));
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int prow = rr + RPT * i;
+      sA[buf][swz(prow, cc)] = ar[i];
+      sB[buf][swz(prow, cc)] = br[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (mend - mbeg + KP - 1) / KP;
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ks++) {
+    const int cur = ks & 1;
+    const bool more = (ks + 1) < nk;
+    if (more) gload();
+    if constexpr (BF16) {
+      const char* bA = reinterpret_cast<const char*>(&sA[cur][0]);
+      const char* bB = reinterpret_cast<const char*>(&sB[cur][0]);
+      const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+      for (int kk = 0; kk < KP / 32; kk++) {
+        bf16x8 af[4], bf[4];
+        // rows 8g+qq (h=0) and 8g+4+qq (h=1) of this 32-pixel block; the swizzle key does not
+        // depend on h, so both reads share one address register (+1024 bytes).
+        const int prow = kk * 32 + 8 * g + qq;
+        const int key = (prow & 3) | ((prow >> 1) & 4);
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+          const char* pa = bA + prow * ROWB + (((waI * 4 + f) ^ key) * 32) + pp * 8;
+          const char* pb = bB + prow * ROWB + (((wbI * 4 + f) ^ key) * 32) + pp * 8;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + 4 * ROWB));
+          af[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          bf[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+      const float* fA = reinterpret_cast<const float*>(&sA[cur][0]);
+      const float* fB = reinterpret_cast<const float*>(&sB[cur][0]);
+      const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int kk = 0; kk < KP / 4; kk++) {
+        const int prow = kk * 4 + g;
+        float af[4], bf[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+          const int cha = waI * 64 + f * 16 + i16;
+          const int chb = wbI * 64 + f * 16 + i16;
+          af[f] = fA[swz(prow, cha >> 2) * 4 + (cha & 3)];
+          bf[f] = fB[swz(prow, chb >> 2) * 4 + (chb & 3)];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row = a-channel (lane>>4)*4+j][col = lane&15]
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ncols = p.nchunks * V;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int ca = at * 128 + waI * 64 + a * 16 + fg * 4 + j;
+      if (ca >= p.CaRows) continue;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int col = bt * 128 + wbI * 64 + b * 16 + fr;
+        if (col >= ncols) continue;
+        atomicAdd(p.out + (size_t)ca * ncols + col, acc[a][b][j]);
+      }
+    }
+  }
+}
+
+int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s) {
+  MT_CHECK(p.ntaps <= 64, "wgrad: %d taps > 64", p.ntaps);
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int ncols = p.nchunks * V;
+  dim3 grid(cdiv(p.CaRows, 128) * cdiv(ncols, 128), nsplit);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, p);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight (un)packing between the reference layouts and [row][tap][col] tiles
+// ------------------------------------------------------------------------------------------
+// pack[r][t][c] = (r<R && c<C) ? w[r*sr + c*sc + kh[t]*kW + kw[t]] : 0, r<Rp, c<Cp
+template <bool BF16>
+__global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out, PackParams p) {
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if constexpr (BF16) reinterpret_cast<unsigned short*>(out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(out)[i] = v;
+  }
+}
+int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s) {
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)4096, (total + 255) / 256);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((pack_kernel<true>), dim3(blocks), dim3(256), 0, s, w, out, p);
+  else hipLaunchKernelGGL((pack_kernel<false>), dim3(blocks), dim3(256), 0, s, w, out, p);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+// dw[r*sr + c*sc + kh[t]*kW + kw[t]] = src[r][t][c]   (r<R, c<C; src rows have Cp columns)
+__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p) {
+  const long total = (long)p.R * p.ntaps * p.C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.C);
+    const long rt = i / p.C;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    dw[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]] = src[((long)r * p.ntaps + t) * p.Cp + c];
+  }
+}
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, hipStream_t s) {
+  const long total = (long)p.R * p.ntaps * p.C;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// adjoint of ReflectionPad2d: fold the gradient of the padded map back onto the interior.
+// src: [N][H+2P][W+2P][Cp], dst: [N][H][W][Cp]
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ void reflect_fold_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H,
+                                    int W, int cchunks, int P) {
+  const long total = (long)N * H * W * cchunks;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cchunks);
+    long t = i / cchunks;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    // pre-images of h in padded coordinates
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + P;
+    if (h >= 1 && h <= P) hs[nh++] = P - h;
+    if (h <= H - 2 && h >= H - 1 - P) hs[nh++] = P + 2 * (H - 1) - h;
+    ws[nw++] = w + P;
+    if (w >= 1 && w <= P) ws[nw++] = P - w;
+    if (w <= W - 2 && w >= W - 1 - P) ws[nw++] = P + 2 * (W - 1) - w;
+    float accv[Elem<BF16>::V];
+#pragma unroll
+    for (int e = 0; e < Elem<BF16>::V; e++) accv[e] = 0.f;
+    for (int a = 0; a < nh; a++)
+      for (int b = 0; b < nw; b++) {
+        const u32x4 v = src[(((long)n * Hp + hs[a]) * Wp + ws[b]) * cchunks + cq];
+        float f[Elem<BF16>::V];
+        Elem<BF16>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < Elem<BF16>::V; e++) accv[e] += f[e];
+      }
+    dst[i] = Elem<BF16>::pack(accv);
+  }
+}
+int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
+                           hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  const long total = (long)N * H * W * cchunks;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)65535, (total + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((reflect_fold_kernel<true>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
+  else
+    hipLaunchKernelGGL((reflect_fold_kernel<false>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// bias gradient: db[c] = sum over pixels of dy[pixel][c]   (fp32 atomics into zeroed db)
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ db, long npix, int cchunks,
+                              int C, int pix_per_block) {
+  constexpr int V = Elem<BF16>::V;
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  if (pl >= npl) return;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  const long p1 = min(npix, p0 + pix_per_block);
+  float accv[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) accv[e] = 0.f;
+  for (long px = p0 + pl; px < p1; px += npl) {
+    float f[V];
+    Elem<BF16>::unpack(dy[px * cchunks + cq], f);
+#pragma unroll
+    for (int e = 0; e < V; e++) accv[e] += f[e];
+  }
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    const int ch = cq * V + e;
+    if (ch < C) atomicAdd(db + ch, accv[e]);
+  }
+}
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  MT_CHECK(cchunks <= 1024, "colsum: too many channels %d", Cp);
+  if (hipMemsetAsync(db, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("colsum memset failed"); return 2; }
+  if (npix == 0) return 0;
+  int threads = 256;
+  while (threads < cchunks) threads *= 2;
+  const int ppb = 2048;
+  const int blocks = (int)((npix + ppb - 1) / ppb);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, db, npix, cchunks, C, ppb);
+  else
+    hipLaunchKernelGGL((colsum_kernel<false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, db, npix, cchunks, C, ppb);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,65 @@
+// Kernel parameter blocks shared between the host-side problem builders (conv_api.hip) and
+// the device kernels (conv_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define MT_MAX_TAPS 64
+
+struct IgemmParams {
+  const char* x;      // gathered operand, NHWC [N][Hi][Wi][Cib bytes]
+  const char* w;      // packed weights [CoRows][nchunks * 16 bytes]
+  const float* bias;  // optional fp32 [nbias]
+  char* y;            // output NHWC [N][Hout][Wout][Co]
+  int N, Hi, Wi;
+  int Cib;            // bytes per input pixel (padded channels * element size)
+  int Ho, Wo, M;      // GEMM pixel grid, M = N*Ho*Wo
+  int Co;             // padded output channels (elements per output pixel)
+  int CoRows;         // rows of the weight pack (== Co)
+  int nbias;
+  int Hout, Wout;     // output tensor spatial size
+  int os, oh0, ow0;   // output pixel = (ho*os + oh0, wo*os + ow0); out-of-range pixels are skipped
+  int is;             // input base coordinate = ho*is (+ dh[tap])
+  int ntaps;
+  int cpc;            // 16-byte chunks per tap
+  int nchunks;        // ntaps * cpc
+  int pad_mode;
+  int act;
+  float slope;
+  short dh[MT_MAX_TAPS];
+  short dw[MT_MAX_TAPS];
+};
+
+struct WgradParams {
+  const char* a;   // pixel-major [M][Cab bytes]: its channels become output rows
+  const char* b;   // gathered NHWC [N][Hi][Wi][Cbb bytes]: (tap, channel) become output columns
+  float* out;      // fp32 [CaRows][nchunks * V]; accumulated with atomics (caller zeroes)
+  int N, Hi, Wi;
+  int Cab, Cbb;    // bytes per pixel
+  int CaRows;      // padded channel count of a
+  int Ho, Wo, M;   // pixel grid of a
+  int is;
+  int ntaps, cpc, nchunks;
+  int pad_mode;
+  int mchunk;      // pixels per split
+  short dh[MT_MAX_TAPS];
+  short dw[MT_MAX_TAPS];
+};
+
+struct PackParams {
+  int R, C;      // logical rows / cols
+  int Rp, Cp;    // padded rows / cols of the packed image
+  long sr, sc;   // element strides of (row, col) in the reference-layout weight tensor
+  int kW;        // filter width (tap element offset = kh*kW + kw)
+  int ntaps;
+  short kh[MT_MAX_TAPS];
+  short kw[MT_MAX_TAPS];
+};
+
+int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
+int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
+int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, hipStream_t s);
+int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
+                           hipStream_t s);
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s);

@@ -1,0 +1,259 @@
+// Scalar loss reductions and their gradients (fp32 accumulation, wavefront-shuffle reduce,
+// one fp32 atomic per wave into the zeroed scalar).
+// Reference: GANLoss vanilla = BCEWithLogitsLoss vs constant 0/1 (loss.py:52-64),
+// classification BCEWithLogitsLoss vs one-hot (adain_model.py:74), L1Loss (303-305,379-380),
+// _l2_regularize (396-399), reparameterize (networks.py:130-135), KL sum (adain_model.py:313-314).
+#include "mt_common.h"
+
+#define RED_GRID(total) (int)min((long)1024, ((long)(total) + 255) / 256)
+
+__device__ __forceinline__ void wave_atomic_add(float* dst, float v) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+}
+// numerically stable BCE-with-logits: max(x,0) - x*t + log(1+exp(-|x|))
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+static int zero_scalar(float* p, hipStream_t s) {
+  if (hipMemsetAsync(p, 0, sizeof(float), s) != hipSuccess) { mt_set_error("loss: memset failed"); return 2; }
+  return 0;
+}
+
+// ---- BCE vs constant target on an NHWC-padded map -------------------------------------------
+template <bool BF16>
+__global__ void bce_const_fwd_kernel(const void* __restrict__ x, float t, float* __restrict__ loss, long npix,
+                                     int C, int Cp, float inv_count) {
+  const long total = npix * C;
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / C;
+    const int c = (int)(i % C);
+    float v;
+    if constexpr (BF16) v = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(x)[px * Cp + c]);
+    else v = reinterpret_cast<const float*>(x)[px * Cp + c];
+    a += bce_logits(v, t);
+  }
+  wave_atomic_add(loss, a * inv_count);
+}
+template <bool BF16>
+__global__ void bce_const_bwd_kernel(const void* __restrict__ x, float t, const float* __restrict__ gscale,
+                                     void* __restrict__ dx, long npix, int C, int Cp, float inv_count) {
+  const long total = npix * Cp;
+  const float gs = gscale[0] * inv_count;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    float g = 0.f;
+    if (c < C) {
+      float v;
+      if constexpr (BF16) v = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(x)[i]);
+      else v = reinterpret_cast<const float*>(x)[i];
+      g = (sigmoidf(v) - t) * gs;
+    }
+    if constexpr (BF16) reinterpret_cast<unsigned short*>(dx)[i] = f32_to_bf16_bits(g);
+    else reinterpret_cast<float*>(dx)[i] = g;
+  }
+}
+extern "C" int mt_bce_const_fwd(int dtype, const void* x, float t, float* loss, size_t npix, int C, int Cp,
+                                mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (zero_scalar(loss, s)) return 2;
+  const long total = (long)npix * C;
+  if (total == 0) return 0;
+  const float inv = 1.f / (float)total;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((bce_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv);
+  else hipLaunchKernelGGL((bce_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_bce_const_bwd(int dtype, const void* x, float t, const float* gscale, void* dx, size_t npix,
+                                int C, int Cp, mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  const long total = (long)npix * Cp;
+  if (total == 0) return 0;
+  const float inv = 1.f / (float)((long)npix * C);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((bce_const_bwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, gscale, dx, (long)npix, C, Cp, inv);
+  else hipLaunchKernelGGL((bce_const_bwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, gscale, dx, (long)npix, C, Cp, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- BCE vs per-element target, fp32 vectors ---------------------------------------------------
+__global__ void bce_target_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                      float* __restrict__ loss, long n, float inv) {
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    a += bce_logits(x[i], t[i]);
+  wave_atomic_add(loss, a * inv);
+}
+__global__ void bce_target_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                      const float* __restrict__ gscale, float* __restrict__ dx, long n,
+                                      float inv) {
+  const float gs = gscale[0] * inv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = (sigmoidf(x[i]) - t[i]) * gs;
+}
+extern "C" int mt_bce_target_fwd(const float* x, const float* t, float* loss, size_t n, mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (zero_scalar(loss, s)) return 2;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bce_target_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, x, t, loss, (long)n, 1.f / (float)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_bce_target_bwd(const float* x, const float* t, const float* gscale, float* dx, size_t n,
+                                 mt_stream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bce_target_bwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, (hipStream_t)st, x, t, gscale, dx, (long)n, 1.f / (float)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- L1 / mean-square over padded tensors (pad elements are zero in both operands) ---------
+template <bool BF16, int MODE>  // MODE 0: |a-b|, 1: a^2
+__global__ void absdiff_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                   float* __restrict__ loss, long nchunks, float inv) {
+  constexpr int V = Elem<BF16>::V;
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float f[V], g[V];
+    Elem<BF16>::unpack(a[i], f);
+    if constexpr (MODE == 0) {
+      Elem<BF16>::unpack(b[i], g);
+#pragma unroll
+      for (int e = 0; e < V; e++) acc += fabsf(f[e] - g[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; e++) acc += f[e] * f[e];
+    }
+  }
+  wave_atomic_add(loss, acc * inv);
+}
+template <bool BF16, int MODE>
+__global__ void absdiff_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                   const float* __restrict__ gscale, u32x4* __restrict__ da,
+                                   u32x4* __restrict__ db, long nchunks, float inv) {
+  constexpr int V = Elem<BF16>::V;
+  const float gs = gscale[0] * inv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float f[V], g[V];
+    Elem<BF16>::unpack(a[i], f);
+    if constexpr (MODE == 0) {
+      Elem<BF16>::unpack(b[i], g);
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        const float d = f[e] - g[e];
+        f[e] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+        g[e] = -f[e];
+      }
+      if (da) da[i] = Elem<BF16>::pack(f);
+      if (db) db[i] = Elem<BF16>::pack(g);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; e++) f[e] = 2.f * f[e] * gs;
+      da[i] = Elem<BF16>::pack(f);
+    }
+  }
+}
+template <int MODE>
+static int absdiff_fwd(int dtype, const void* a, const void* b, float* loss, size_t n, size_t count, hipStream_t s) {
+  if (zero_scalar(loss, s)) return 2;
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  MT_CHECK(n % V == 0, "loss: element count %zu not a multiple of %d", n, V);
+  const long nc = (long)(n / V);
+  if (nc == 0 || count == 0) return 0;
+  const float inv = 1.f / (float)count;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((absdiff_fwd_kernel<true, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv);
+  else hipLaunchKernelGGL((absdiff_fwd_kernel<false, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+template <int MODE>
+static int absdiff_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, void* db, size_t n,
+                       size_t count, hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  MT_CHECK(n % V == 0, "loss: element count %zu not a multiple of %d", n, V);
+  const long nc = (long)(n / V);
+  if (nc == 0 || count == 0) return 0;
+  const float inv = 1.f / (float)count;
+  const int grid = (int)min((long)16384, (nc + 255) / 256);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((absdiff_bwd_kernel<true, MODE>), dim3(grid), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, gscale, (u32x4*)da, (u32x4*)db, nc, inv);
+  else hipLaunchKernelGGL((absdiff_bwd_kernel<false, MODE>), dim3(grid), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, gscale, (u32x4*)da, (u32x4*)db, nc, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_l1_fwd(int dtype, const void* a, const void* b, float* loss, size_t n, size_t count, mt_stream_t s) {
+  return absdiff_fwd<0>(dtype, a, b, loss, n, count, (hipStream_t)s);
+}
+extern "C" int mt_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, void* db, size_t n,
+                         size_t count, mt_stream_t s) {
+  return absdiff_bwd<0>(dtype, a, b, gscale, da, db, n, count, (hipStream_t)s);
+}
+extern "C" int mt_l2mean_fwd(int dtype, const void* x, float* loss, size_t n, size_t count, mt_stream_t s) {
+  return absdiff_fwd<1>(dtype, x, nullptr, loss, n, count, (hipStream_t)s);
+}
+extern "C" int mt_l2mean_bwd(int dtype, const void* x, const float* gscale, void* dx, size_t n, size_t count,
+                             mt_stream_t s) {
+  return absdiff_bwd<1>(dtype, x, nullptr, gscale, dx, nullptr, n, count, (hipStream_t)s);
+}
+
+// ---- VAE branch ---------------------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ z, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    z[i] = eps[i] * expf(0.5f * logvar[i]) + mu[i];
+}
+__global__ void reparam_bwd_kernel(const float* __restrict__ logvar, const float* __restrict__ eps,
+                                   const float* __restrict__ dz, float* __restrict__ dmu,
+                                   float* __restrict__ dlogvar, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    dmu[i] = dz[i];
+    dlogvar[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+  }
+}
+extern "C" int mt_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, mt_stream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, (hipStream_t)s, mu, logvar, eps, z, (long)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_reparam_bwd(const float* logvar, const float* eps, const float* dz, float* dmu, float* dlogvar,
+                              size_t n, mt_stream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, (hipStream_t)s, logvar, eps, dz, dmu, dlogvar, (long)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                              float* __restrict__ kl, long n) {
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    a += 1.f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
+  wave_atomic_add(kl, -0.5f * a);
+}
+__global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                              const float* __restrict__ gscale, float* __restrict__ dmu,
+                              float* __restrict__ dlogvar, long n) {
+  const float gs = gscale[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    dmu[i] = gs * mu[i];
+    dlogvar[i] = gs * -0.5f * (1.f - expf(logvar[i]));
+  }
+}
+extern "C" int mt_kl_fwd(const float* mu, const float* logvar, float* kl, size_t n, mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (zero_scalar(kl, s)) return 2;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, mu, logvar, kl, (long)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_kl_bwd(const float* mu, const float* logvar, const float* gscale, float* dmu, float* dlogvar,
+                         size_t n, mt_stream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, (hipStream_t)s, mu, logvar, gscale, dmu, dlogvar, (long)n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,113 @@
+// Small fp32 kernels: nn.Linear on style codes (latency-bound, M <= 64 rows), the fused
+// multi-tensor Adam step, and the library's error plumbing.
+// Reference: nn.Linear (networks.py:127-128,256-261; norm.py:27), torch.optim.Adam with
+// L2-coupled weight decay (adain_model.py:57-61,68-71).
+#include "mt_common.h"
+#include <string.h>
+
+// ---- error plumbing -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void mt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mt_last_error(void) { return g_err; }
+extern "C" int mt_version(void) { return 1; }
+
+// ---- Linear: y[n][o] = act(sum_i x[n][i] * w[o][i] + b[o]) --------------------------------
+// one wave per output element; lanes stride the reduction and shuffle-reduce.
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ b, float* __restrict__ y, int n, int in, int out,
+                                  int act) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * out) return;
+  const int r = wave / out, o = wave % out;
+  float a = 0.f;
+  for (int i = lane; i < in; i += 64) a += x[(long)r * in + i] * w[(long)o * in + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (b) a += b[o];
+    y[wave] = act_apply(a, act, 0.01f);
+  }
+}
+extern "C" int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in, int out,
+                             int act, mt_stream_t s) {
+  const long waves = (long)n * out;
+  if (waves == 0) return 0;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, (hipStream_t)s, x, w, b, y, n, in, out, act);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+// dx[n][i] = sum_o dy[n][o] w[o][i];  dw[o][i] = sum_n dy[n][o] x[n][i];  db[o] = sum_n dy[n][o]
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                     float* __restrict__ dx, int n, int in, int out) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)n * in) return;
+  const int r = (int)(idx / in), i = (int)(idx % in);
+  float a = 0.f;
+  for (int o = 0; o < out; o++) a += dy[(long)r * out + o] * w[(long)o * in + i];
+  dx[idx] = a;
+}
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                     float* __restrict__ dw, float* __restrict__ db, int n, int in, int out) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)out * in) return;
+  const int o = (int)(idx / in), i = (int)(idx % in);
+  float a = 0.f, bsum = 0.f;
+  for (int r = 0; r < n; r++) {
+    const float g = dy[(long)r * out + o];
+    a += g * x[(long)r * in + i];
+    bsum += g;
+  }
+  dw[idx] = a;
+  if (db && i == 0) db[o] = bsum;
+}
+extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                             int n, int in, int out, mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (n == 0) return 0;
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)n * in, 256)), dim3(256), 0, s, w, dy, dx, n, in, out);
+  if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)out * in, 256)), dim3(256), 0, s, x, dy, dw, db, n, in, out);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- fused multi-tensor Adam -----------------------------------------------------------------
+// grid = (chunks, tensors).  torch.optim.Adam semantics (no amsgrad, maximize=False):
+//   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+//   p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr,
+                                  float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = (float*)ptrs[4 * t + 0];
+  const float* __restrict__ g = (const float*)ptrs[4 * t + 1];
+  float* __restrict__ m = (float*)ptrs[4 * t + 2];
+  float* __restrict__ v = (float*)ptrs[4 * t + 3];
+  const long n = sizes[t];
+  const float step_size = lr / bc1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = g[i] + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+extern "C" int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float lr,
+                             float beta1, float beta2, float eps, float wd, int step, mt_stream_t s) {
+  if (count == 0) return 0;
+  MT_CHECK(step >= 1, "adam: step must be >= 1");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  int chunks = (int)((max_size + 256 * 8 - 1) / (256 * 8));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 2048) chunks = 2048;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, lr, beta1, beta2, eps, wd, bc1, bc2);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

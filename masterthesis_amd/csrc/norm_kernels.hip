@@ -1,0 +1,329 @@
+// Normalisation family for NHWC tensors: InstanceNorm2d(affine=False) (+ReLU/LeakyReLU),
+// AdaptiveInstanceNorm ((1+gamma)*IN(x)+beta, +ReLU, +residual) and the reference's custom
+// per-sample LayerNorm with per-channel affine (+ReLU).
+// Reference: functions.py:17,32-34; norm.py:5-33; blocks.py:38-42,83-87,158-167.
+//
+// All three share the same four HBM passes:
+//   forward : mt_nc_stats (sum, sum^2 per (n,c))  ->  mt_norm_finalize (tiny)  ->
+//             mt_scale_shift_act  y = act(scale[n,c]*x + shift[n,c]) (+res)
+//   backward: mt_nc_stats_bwd (sum g, sum g*x)    ->  mt_norm_bwd_finalize (tiny) ->
+//             mt_norm_bwd_apply   dx = c1[n,c]*g + c2[n,c] + c3[n,c]*x,  g = dy*act'(.)
+// Statistics are fp32; per-thread partial sums, LDS tree over the pixel lanes of a block,
+// then one fp32 atomic per (block, channel).
+#include "mt_common.h"
+
+// block = cchunks channel-chunks x npl pixel lanes.  grid = (pixel blocks, N)
+template <bool BF16, bool BWD>
+__global__ __launch_bounds__(256) void nc_stats_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ sums,
+                                                       int HW, int cchunks, int pix_per_block, int act,
+                                                       float slope) {
+  constexpr int V = Elem<BF16>::V;
+  __shared__ float red[256 * 2];
+  const int n = blockIdx.y;
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  const int Cp = cchunks * V;
+  const long base = (long)n * HW * cchunks;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float s1[V], s2[V], sc[V], sh[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) { s1[e] = 0.f; s2[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+  if (BWD && pl < npl) {
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      sc[e] = scale[(long)n * Cp + cq * V + e];
+      sh[e] = shift[(long)n * Cp + cq * V + e];
+    }
+  }
+  if (pl < npl) {
+    for (int px = p0 + pl; px < p1; px += npl) {
+      float f[V];
+      Elem<BF16>::unpack(x[base + (long)px * cchunks + cq], f);
+      if constexpr (BWD) {
+        float g[V];
+        Elem<BF16>::unpack(dy[base + (long)px * cchunks + cq], g);
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+          const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
+          s1[e] += gg;
+          s2[e] += gg * f[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+      }
+    }
+  }
+  // reduce over pixel lanes through LDS, one element at a time (small: V*2 rounds)
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    __syncthreads();
+    red[threadIdx.x * 2] = s1[e];
+    red[threadIdx.x * 2 + 1] = s2[e];
+    __syncthreads();
+    if (pl == 0) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < npl; k++) { a += red[(k * cchunks + cq) * 2]; b += red[(k * cchunks + cq) * 2 + 1]; }
+      float* dst = sums + ((long)n * Cp + cq * V + e) * 2;
+      atomicAdd(dst, a);
+      atomicAdd(dst + 1, b);
+    }
+  }
+}
+
+template <bool BWD>
+static int launch_stats(int dtype, const void* x, const void* dy, const float* scale, const float* shift,
+                        float* sums, int N, int HW, int Cp, int act, float slope, hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  MT_CHECK(Cp % 8 == 0 && cchunks >= 1 && cchunks <= 256, "nc_stats: unsupported channel count %d", Cp);
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)N * Cp, s) != hipSuccess) {
+    mt_set_error("nc_stats: memset failed");
+    return 2;
+  }
+  const int npl = 256 / cchunks;
+  int ppb = npl * 32;  // 32 pixels per thread
+  if (ppb < 64) ppb = 64;
+  dim3 grid(cdiv(HW, ppb), N);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+  else
+    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s) {
+  return launch_stats<false>(dtype, x, nullptr, nullptr, nullptr, sums, N, HW, Cp, 0, 0.f, (hipStream_t)s);
+}
+extern "C" int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale, const float* shift,
+                               float* sums2, int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
+  return launch_stats<true>(dtype, x, dy, scale, shift, sums2, N, HW, Cp, act, slope, (hipStream_t)s);
+}
+
+// one block per sample; threads stride over channels
+__global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, const float* __restrict__ gb,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* __restrict__ scale, float* __restrict__ shift,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int HW, int C, int Cp,
+                                     float eps) {
+  const int n = blockIdx.x;
+  __shared__ float red[2][4];
+  __shared__ float bc[2];
+  float lmean = 0.f, lrstd = 0.f;
+  if (mode == MT_NORM_LAYER) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      a += sums[((long)n * Cp + c) * 2];
+      b += sums[((long)n * Cp + c) * 2 + 1];
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ta = 0.f, tb = 0.f;
+      for (int k = 0; k < (int)(blockDim.x >> 6); k++) { ta += red[0][k]; tb += red[1][k]; }
+      const float cnt = (float)C * (float)HW;
+      const float m = ta / cnt;
+      float var = tb / cnt - m * m;
+      var = var > 0.f ? var : 0.f;
+      bc[0] = m; bc[1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    lmean = bc[0]; lrstd = bc[1];
+  }
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const long i = (long)n * Cp + c;
+    float m = 0.f, r = 0.f, sc = 0.f, sh = 0.f;
+    if (c < C) {
+      if (mode == MT_NORM_LAYER) {
+        m = lmean; r = lrstd;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        sc = r * g; sh = b - m * r * g;
+      } else {
+        m = sums[i * 2] / (float)HW;
+        float var = sums[i * 2 + 1] / (float)HW - m * m;
+        var = var > 0.f ? var : 0.f;
+        r = rsqrtf(var + eps);
+        float a = 1.f, b = 0.f;
+        if (mode == MT_NORM_ADAIN) { a = 1.f + gb[(long)n * 2 * C + c]; b = gb[(long)n * 2 * C + C + c]; }
+        sc = r * a; sh = b - m * r * a;
+      }
+    }
+    scale[i] = sc; shift[i] = sh; mean[i] = m; rstd[i] = r;
+  }
+}
+extern "C" int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* gamma,
+                                const float* beta, float* scale, float* shift, float* mean, float* rstd, int N,
+                                int HW, int C, int Cp, float eps, mt_stream_t s) {
+  MT_CHECK(mode != MT_NORM_ADAIN || gb != nullptr, "norm_finalize: adain needs gb");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, mode, sums, gb, gamma, beta, scale, shift, mean, rstd, HW, C, Cp, eps);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = act(scale*x + shift) (+res); elementwise over 16-byte chunks. grid-stride.
+template <bool BF16>
+__global__ void scale_shift_act_kernel(const u32x4* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const u32x4* __restrict__ res,
+                                       u32x4* __restrict__ y, long total, int HW, int cchunks, int act,
+                                       float slope) {
+  constexpr int V = Elem<BF16>::V;
+  const long per_img = (long)HW * cchunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_img);
+    const int cq = (int)(i % cchunks);
+    const float* sc = scale + ((long)n * cchunks + cq) * V;
+    const float* sh = shift + ((long)n * cchunks + cq) * V;
+    float f[V], r[V];
+    Elem<BF16>::unpack(x[i], f);
+    if (res) Elem<BF16>::unpack(res[i], r);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      float v = act_apply(sc[e] * f[e] + sh[e], act, slope);
+      if (res) v += r[e];
+      f[e] = v;
+    }
+    y[i] = Elem<BF16>::pack(f);
+  }
+}
+extern "C" int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
+                                  const void* res, void* y, int N, int HW, int Cp, int act, float slope,
+                                  mt_stream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  const long total = (long)N * HW * cchunks;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)16384, (total + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((scale_shift_act_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, total, HW, cchunks, act, slope);
+  else
+    hipLaunchKernelGGL((scale_shift_act_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, total, HW, cchunks, act, slope);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward coefficients.  With xh = (x-m)*r, a = per-(n,c) multiplier of xh in the forward
+// (1, 1+gamma_adain or gamma_layer), S1 = sum g, S2 = sum g*x over the pixels:
+//   sum g*xh = r*(S2 - m*S1)
+//   INSTANCE/ADAIN: dx = r*a*(g - S1/HW - xh * sum(g*xh)/HW)
+//   LAYER         : dx = r*(a*g - A/(C*HW) - xh * B/(C*HW)),  A = sum_c a_c*S1_c, B = sum_c a_c*sum(g*xh)_c
+__global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sums2,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ gb, const float* __restrict__ gamma,
+                                         float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
+                                         float* __restrict__ dgb, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta, int HW, int C, int Cp) {
+  const int n = blockIdx.x;
+  __shared__ float red[2][4];
+  __shared__ float bc[2];
+  float LA = 0.f, LB = 0.f;
+  if (mode == MT_NORM_LAYER) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const long i = (long)n * Cp + c;
+      const float S1 = sums2[i * 2], S2 = sums2[i * 2 + 1];
+      const float gxh = rstd[i] * (S2 - mean[i] * S1);
+      const float g = gamma ? gamma[c] : 1.f;
+      a += g * S1; b += g * gxh;
+      if (dgamma) atomicAdd(dgamma + c, gxh);
+      if (dbeta) atomicAdd(dbeta + c, S1);
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ta = 0.f, tb = 0.f;
+      for (int k = 0; k < (int)(blockDim.x >> 6); k++) { ta += red[0][k]; tb += red[1][k]; }
+      bc[0] = ta; bc[1] = tb;
+    }
+    __syncthreads();
+    LA = bc[0]; LB = bc[1];
+  }
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const long i = (long)n * Cp + c;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (c < C) {
+      const float m = mean[i], r = rstd[i];
+      const float S1 = sums2[i * 2], S2 = sums2[i * 2 + 1];
+      const float gxh = r * (S2 - m * S1);
+      if (mode == MT_NORM_LAYER) {
+        const float g = gamma ? gamma[c] : 1.f;
+        const float cnt = (float)C * (float)HW;
+        // dx = r*g*gval - r*LA/cnt - r*(x-m)*r*LB/cnt
+        k1 = r * g;
+        k3 = -r * r * LB / cnt;
+        k2 = -r * LA / cnt - k3 * m;
+      } else {
+        float a = 1.f;
+        if (mode == MT_NORM_ADAIN) {
+          a = 1.f + gb[(long)n * 2 * C + c];
+          dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
+          dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
+        }
+        const float hw = (float)HW;
+        k1 = r * a;
+        k3 = -r * a * r * gxh / hw;
+        k2 = -r * a * S1 / hw - k3 * m;
+      }
+    }
+    c1[i] = k1; c2[i] = k2; c3[i] = k3;
+  }
+}
+extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const float* rstd,
+                                    const float* gb, const float* gamma, float* c1, float* c2, float* c3,
+                                    float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,
+                                    mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_finalize: adain needs gb/dgb");
+  if (mode == MT_NORM_LAYER) {
+    if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("memset"); return 2; }
+    if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("memset"); return 2; }
+  }
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, dgamma, dbeta, HW, C, Cp);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool BF16>
+__global__ void norm_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                      const float* __restrict__ c1, const float* __restrict__ c2,
+                                      const float* __restrict__ c3, u32x4* __restrict__ dx, long total, int HW,
+                                      int cchunks, int act, float slope) {
+  constexpr int V = Elem<BF16>::V;
+  const long per_img = (long)HW * cchunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_img);
+    const int cq = (int)(i % cchunks);
+    const long o = ((long)n * cchunks + cq) * V;
+    float f[V], g[V];
+    Elem<BF16>::unpack(x[i], f);
+    Elem<BF16>::unpack(dy[i], g);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float gg = g[e] * act_grad_z(scale[o + e] * f[e] + shift[o + e], act, slope);
+      f[e] = c1[o + e] * gg + c2[o + e] + c3[o + e] * f[e];
+    }
+    dx[i] = Elem<BF16>::pack(f);
+  }
+}
+extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
+                                 const float* shift, const float* c1, const float* c2, const float* c3, void* dx,
+                                 int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  const long total = (long)N * HW * cchunks;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)16384, (total + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, total, HW, cchunks, act, slope);
+  else
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, total, HW, cchunks, act, slope);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,743 @@
+"""Autograd-visible ops of the hot path, each a thin wrapper over one or more C-ABI entry
+points of ``libmt_hip.so`` (``include/mt_api.h``).  PyTorch supplies device memory, the
+stream and the autograd tape; all arithmetic happens in the HIP library.
+
+Tensor convention ("canonical"): a 4-D activation is a logical NCHW tensor whose memory is
+NHWC with the channel count padded to a multiple of 8 (strides ``(H*W*Cp, 1, W*Cp, Cp)``),
+pad channels zero.  So module code reads exactly like the reference's (``torch.cat(..., 0)``,
+``torch.split``, ``.size(1)``) while kernels see 16-byte aligned channel vectors.  Tensors in
+any other layout/dtype are converted once on entry (``canon``).  2-D tensors (style codes,
+class vectors, MLP activations) are plain fp32 row-major.
+
+There is deliberately no CPU path: ops raise if handed a non-HIP tensor.
+"""
+import ctypes as C
+import contextlib
+
+import torch
+
+from . import _lib as L
+
+_STATE = {"dtype": torch.float32}
+
+
+def set_compute_dtype(dtype):
+    """Storage dtype of activations: torch.float32 (parity path) or torch.bfloat16."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"unsupported compute dtype {dtype}")
+    _STATE["dtype"] = dtype
+
+
+def compute_dtype():
+    return _STATE["dtype"]
+
+
+def padc(c):
+    return (c + 7) & ~7
+
+
+def _mt(dtype):
+    return L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_hip(t):
+    if not t.is_cuda:
+        raise RuntimeError("masterthesis_amd ops run on the HIP device only (there is no CPU fallback); "
+                           f"got a tensor on {t.device}")
+
+
+def new_act(N, Cc, H, W, dtype, device, zero=False):
+    """Allocate a canonical activation and return its logical NCHW view."""
+    alloc = torch.zeros if zero else torch.empty
+    buf = alloc((N, H, W, padc(Cc)), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def is_canonical(t):
+    if t.dim() != 4 or not t.is_cuda:
+        return False
+    N, Cc, H, W = t.shape
+    Cp = padc(Cc)
+    want = (H * W * Cp, 1, W * Cp, Cp)
+    for size, st, w in zip(t.shape, t.stride(), want):
+        if size > 1 and st != w:
+            return False
+    return t.data_ptr() % 16 == 0
+
+
+def canon(t, dtype=None):
+    """Return ``t`` in canonical layout and compute dtype (no copy if it already is)."""
+    dtype = dtype or compute_dtype()
+    _need_hip(t)
+    if t.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got shape {tuple(t.shape)}")
+    if t.dtype == dtype and is_canonical(t):
+        return t
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    N, Cc, H, W = t.shape
+    out = new_act(N, Cc, H, W, dtype, t.device)
+    sn, sc, sh, sw = t.stride()
+    L.check(L.load().mt_to_nhwc(_mt(t.dtype), _ptr(t), sn, sc, sh, sw, _mt(dtype), _ptr(out), N, Cc, H, W,
+                                _stream()), "mt_to_nhwc")
+    return out
+
+
+def to_nchw_f32(t):
+    """Canonical activation -> dense fp32 NCHW tensor (API boundary / visualisation)."""
+    t = canon(t.detach())
+    N, Cc, H, W = t.shape
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=t.device)
+    L.check(L.load().mt_to_nchw_f32(_mt(t.dtype), _ptr(t), _ptr(out), N, Cc, H, W, _stream()), "mt_to_nchw_f32")
+    return out
+
+
+def _f32c(t):
+    """fp32 contiguous device tensor (2-D / parameter operands)."""
+    _need_hip(t)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+def _act_code(act):
+    return {None: L.ACT_NONE, "none": L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU,
+            "tanh": L.ACT_TANH}[act]
+
+
+# --------------------------------------------------------------------------------------
+# packed-weight cache.  Parameters keep the reference layout (checkpoint compatible); the
+# MFMA tile images are rebuilt only when a parameter changed (optimizer step / load).
+# --------------------------------------------------------------------------------------
+_PACKS = {}
+_EPOCH = {}
+
+
+def bump_epoch(params):
+    """Called by the optimizer after it rewrote parameter memory through raw pointers."""
+    for p in params:
+        k = p.data_ptr()
+        _EPOCH[k] = _EPOCH.get(k, 0) + 1
+
+
+def clear_pack_cache():
+    _PACKS.clear()
+
+
+def _get_pack(weight, desc, which):
+    key = (weight.data_ptr(), which, desc.dtype, desc.transposed, desc.stride, desc.kh, desc.kw)
+    tag = (weight._version, _EPOCH.get(weight.data_ptr(), 0), tuple(weight.shape))
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    lib = L.load()
+    nbytes = lib.mt_conv_pack_bytes(C.byref(desc), which)
+    pack = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=weight.device)
+    L.check(lib.mt_conv_pack(C.byref(desc), which, _ptr(weight), _ptr(pack), _stream()), "mt_conv_pack")
+    _PACKS[key] = (tag, pack)
+    return pack
+
+
+# --------------------------------------------------------------------------------------
+# convolution family
+# --------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        stride, pad, pad_mode, act, slope, transposed, out_pad = cfg
+        lib = L.load()
+        dt = compute_dtype()
+        x = canon(x)
+        weight = _f32c(weight.detach())
+        N, Ci, H, W = x.shape
+        if transposed:
+            Ciw, Co = weight.shape[0], weight.shape[1]
+        else:
+            Co, Ciw = weight.shape[0], weight.shape[1]
+        if Ciw != Ci:
+            raise RuntimeError(f"conv: input has {Ci} channels, weight expects {Ciw}")
+        desc = L.ConvDesc(_mt(dt), int(transposed), N, H, W, Ci, Co, weight.shape[2], weight.shape[3],
+                          stride, pad, pad_mode, out_pad, act, slope)
+        ho, wo = C.c_int(), C.c_int()
+        L.check(lib.mt_conv_out_hw(C.byref(desc), C.byref(ho), C.byref(wo)), "mt_conv_out_hw")
+        y = new_act(N, Co, ho.value, wo.value, dt, x.device)
+        pack = _get_pack(weight, desc, L.PACK_FWD)
+        b = None if bias is None else _f32c(bias.detach())
+        L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()), "mt_conv_fwd")
+        ctx.desc = desc
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, weight, y = ctx.saved_tensors
+        desc = ctx.desc
+        dy = canon(dy)
+        if desc.act != L.ACT_NONE:
+            dz = new_act(*dy.shape, dy.dtype, dy.device)
+            n = dy.shape[0] * dy.shape[2] * dy.shape[3] * padc(dy.shape[1])
+            L.check(lib.mt_act_bwd(desc.dtype, _ptr(dy), _ptr(y), _ptr(dz), n, desc.act, desc.slope, _stream()),
+                    "mt_act_bwd")
+            dy = dz
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            pack = _get_pack(weight, desc, L.PACK_BWD_DATA)
+            nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
+            ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dy.device)
+            dx = new_act(*x.shape, dy.dtype, dy.device)
+            L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
+                    "mt_conv_bwd_data")
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
+            ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+            dw = torch.empty_like(weight)
+            if want_b:
+                db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
+            L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
+                                           _stream()), "mt_conv_bwd_weight")
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01):
+    """act(conv2d(pad(x)) + bias): nn.ReflectionPad2d/zero pad + nn.Conv2d (+ activation)."""
+    pm = L.PAD_REFLECT if (pad_mode == "reflect" and pad > 0) else L.PAD_ZERO
+    return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0))
+
+
+def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
+    """nn.ConvTranspose2d (+ activation); weight layout [Cin, Cout, kh, kw]."""
+    return _Conv.apply(x, weight, bias, (stride, pad, L.PAD_ZERO, _act_code(act), float(slope), True, out_pad))
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32c(x)
+        w = _f32c(weight.detach())
+        b = None if bias is None else _f32c(bias.detach())
+        n, i = x.shape
+        o = w.shape[0]
+        if w.shape[1] != i:
+            raise RuntimeError(f"linear: input has {i} features, weight expects {w.shape[1]}")
+        y = torch.empty((n, o), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), n, i, o, L.ACT_NONE, _stream()),
+                "mt_linear_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, i = x.shape
+        o = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty((o,), dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
+        L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), n, i, o,
+                                       _stream()), "mt_linear_bwd")
+        return dx, (dw if ctx.needs_input_grad[1] else None), db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------
+# normalisation family
+# --------------------------------------------------------------------------------------
+class _Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gb, gamma, beta, res, cfg):
+        mode, act, slope, eps = cfg
+        lib = L.load()
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        Cp, HW = padc(Cc), H * W
+        dev = x.device
+        mt = _mt(x.dtype)
+        sums = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
+        L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
+        coef = torch.empty((4, N, Cp), dtype=torch.float32, device=dev)  # scale, shift, mean, rstd
+        gbc = None if gb is None else _f32c(gb.detach())
+        gm = None if gamma is None else _f32c(gamma.detach())
+        bt = None if beta is None else _f32c(beta.detach())
+        if gbc is not None and tuple(gbc.shape) != (N, 2 * Cc):
+            raise RuntimeError(f"adain: expected style projection of shape {(N, 2 * Cc)}, got {tuple(gbc.shape)}")
+        L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
+                                     _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, _stream()),
+                "mt_norm_finalize")
+        r = None if res is None else canon(res)
+        y = new_act(N, Cc, H, W, x.dtype, dev)
+        L.check(lib.mt_scale_shift_act(mt, _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(r), _ptr(y), N, HW, Cp, act,
+                                       slope, _stream()), "mt_scale_shift_act")
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, coef, gbc, gm)
+        ctx.shapes = (None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        mode, act, slope, eps = ctx.cfg
+        x, coef, gbc, gm = ctx.saved_tensors
+        dy = canon(dy)
+        N, Cc, H, W = x.shape
+        Cp, HW = padc(Cc), H * W
+        dev = x.device
+        mt = _mt(x.dtype)
+        sums2 = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
+        L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
+                                    slope, _stream()), "mt_nc_stats_bwd")
+        cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
+        dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
+        dgamma = dbeta = None
+        if mode == L.NORM_LAYER and gm is not None:
+            dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+        L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
+                                         _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
+                                         _ptr(dbeta), N, HW, Cc, Cp, _stream()), "mt_norm_bwd_finalize")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(N, Cc, H, W, x.dtype, dev)
+            L.check(lib.mt_norm_bwd_apply(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(cc[0]),
+                                          _ptr(cc[1]), _ptr(cc[2]), _ptr(dx), N, HW, Cp, act, slope, _stream()),
+                    "mt_norm_bwd_apply")
+        gshape, bshape = ctx.shapes
+        if dgamma is not None:
+            dgamma = dgamma.view(gshape)
+            dbeta = dbeta.view(bshape)
+        dres = dy if ctx.needs_input_grad[4] else None
+        return dx, dgb, dgamma, dbeta, dres, None
+
+
+def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5):
+    """act(InstanceNorm2d(affine=False)(x)) (+ res)"""
+    return _Norm.apply(x, None, None, None, res, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps)))
+
+
+def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5):
+    """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
+    return _Norm.apply(x, gb, None, None, res, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps)))
+
+
+def layer_norm_act(x, gamma, beta, act=None, slope=0.01, eps=1e-5):
+    """reference LayerNorm (per-sample over C,H,W; per-channel affine) + activation"""
+    return _Norm.apply(x, None, gamma, beta, None, (L.NORM_LAYER, _act_code(act), float(slope), float(eps)))
+
+
+# --------------------------------------------------------------------------------------
+# elementwise / pooling / layout
+# --------------------------------------------------------------------------------------
+def _numel_padded(t):
+    return t.shape[0] * t.shape[2] * t.shape[3] * padc(t.shape[1])
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        if x.dim() == 4:
+            x = canon(x)
+            y = new_act(*x.shape, x.dtype, x.device)
+            n, mt = _numel_padded(x), _mt(x.dtype)
+        else:
+            x = _f32c(x)
+            y = torch.empty_like(x)
+            n, mt = x.numel(), L.MT_F32
+        L.check(L.load().mt_act_fwd(mt, _ptr(x), _ptr(y), n, act, slope, _stream()), "mt_act_fwd")
+        ctx.cfg = (act, slope, n, mt)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope, n, mt = ctx.cfg
+        if y.dim() == 4:
+            dy = canon(dy)
+            dx = new_act(*y.shape, y.dtype, y.device)
+        else:
+            dy = _f32c(dy)
+            dx = torch.empty_like(y)
+        L.check(L.load().mt_act_bwd(mt, _ptr(dy), _ptr(y), _ptr(dx), n, act, slope, _stream()), "mt_act_bwd")
+        return dx, None, None
+
+
+def activation(x, act, slope=0.01):
+    return _Act.apply(x, _act_code(act), float(slope))
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = canon(a), canon(b)
+        if a.shape != b.shape:
+            raise RuntimeError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        y = new_act(*a.shape, a.dtype, a.device)
+        L.check(L.load().mt_add(_mt(a.dtype), _ptr(a), _ptr(b), _ptr(y), _numel_padded(a), _stream()), "mt_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _NoiseAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seed, offset):
+        x = canon(x)
+        y = new_act(*x.shape, x.dtype, x.device)
+        L.check(L.load().mt_gaussian_noise_add(_mt(x.dtype), _ptr(x), _ptr(y), _numel_padded(x), seed, offset,
+                                               _stream()), "mt_gaussian_noise_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+def gaussian_noise_add(x, seed, offset):
+    """x + N(0,1) drawn on device (Philox4x32-10, counter = element index + offset)."""
+    if padc(x.shape[1]) != x.shape[1]:
+        raise RuntimeError("gaussian_noise_add needs a channel count that is a multiple of 8")
+    return _NoiseAdd.apply(x, int(seed), int(offset))
+
+
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        lib = L.load()
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        if kind == 2:
+            Ho, Wo, fn = H // 2, W // 2, lib.mt_avgpool2_fwd
+        else:
+            Ho, Wo, fn = (H - 1) // 2 + 1, (W - 1) // 2 + 1, lib.mt_avgpool3s2_fwd
+        y = new_act(N, Cc, Ho, Wo, x.dtype, x.device)
+        L.check(fn(_mt(x.dtype), _ptr(x), _ptr(y), N, H, W, padc(Cc), _stream()), "mt_avgpool_fwd")
+        ctx.cfg = (kind, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        kind, (N, Cc, H, W) = ctx.cfg
+        dy = canon(dy)
+        dx = new_act(N, Cc, H, W, dy.dtype, dy.device)
+        fn = lib.mt_avgpool2_bwd if kind == 2 else lib.mt_avgpool3s2_bwd
+        L.check(fn(_mt(dy.dtype), _ptr(dy), _ptr(dx), N, H, W, padc(Cc), _stream()), "mt_avgpool_bwd")
+        return dx, None
+
+
+def avg_pool2(x):
+    """nn.AvgPool2d(kernel_size=2, stride=2)"""
+    return _Pool.apply(x, 2)
+
+
+def avg_pool3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)"""
+    return _Pool.apply(x, 3)
+
+
+class _Gap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_gap_fwd(_mt(x.dtype), _ptr(x), _ptr(y), N, H * W, Cc, padc(Cc), _stream()), "mt_gap_fwd")
+        ctx.cfg = (tuple(x.shape), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (N, Cc, H, W), dt = ctx.cfg
+        dy = _f32c(dy)
+        dx = new_act(N, Cc, H, W, dt, dy.device)
+        L.check(L.load().mt_gap_bwd(_mt(dt), _ptr(dy), _ptr(dx), N, H * W, Cc, padc(Cc), _stream()), "mt_gap_bwd")
+        return dx
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool2d(1) followed by flatten: [N,C,H,W] -> fp32 [N,C]"""
+    return _Gap.apply(x)
+
+
+class _CatClass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, cls):
+        img = canon(img)
+        cls = _f32c(cls)
+        N, Cc, H, W = img.shape
+        D = cls.shape[1]
+        out = new_act(N, Cc + D, H, W, img.dtype, img.device)
+        L.check(L.load().mt_cat_class_planes(_mt(img.dtype), _ptr(img), _ptr(cls), _ptr(out), N, H * W, Cc, D,
+                                             _stream()), "mt_cat_class_planes")
+        ctx.cfg = (Cc, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Cc, D = ctx.cfg
+        dout = canon(dout)
+        N, _, H, W = dout.shape
+        dimg = new_act(N, Cc, H, W, dout.dtype, dout.device)
+        L.check(L.load().mt_slice_channels(_mt(dout.dtype), _ptr(dout), _ptr(dimg), N, H * W, Cc + D, Cc, _stream()),
+                "mt_slice_channels")
+        return dimg, None
+
+
+def cat_class_planes(img, cls):
+    """torch.cat([img, cls[:, :, None, None].repeat(1, 1, H, W)], dim=1) (networks.py:138-140)"""
+    return _CatClass.apply(img, cls)
+
+
+class _CatBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [canon(t) for t in ts]
+        _, Cc, H, W = ts[0].shape
+        ns = [t.shape[0] for t in ts]
+        out = new_act(sum(ns), Cc, H, W, ts[0].dtype, ts[0].device)
+        sz = H * W * padc(Cc)
+        flat = out.as_strided((sum(ns) * sz,), (1,))
+        o = 0
+        for t, n in zip(ts, ns):
+            flat[o * sz:(o + n) * sz].copy_(t.as_strided((n * sz,), (1,)))  # raw block copy incl. zero pads
+            o += n
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return tuple(torch.split(dy, ctx.ns, dim=0))
+
+
+def cat_batch(ts):
+    """torch.cat(ts, dim=0) that keeps the padded-NHWC layout (no re-layout pass)."""
+    return _CatBatch.apply(*ts)
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+def _gs(g):
+    return _f32c(g).reshape(1)
+
+
+class _BceConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_bce_const_fwd(_mt(x.dtype), _ptr(x), t, _ptr(loss), N * H * W, Cc, padc(Cc), _stream()),
+                "mt_bce_const_fwd")
+        ctx.t = t
+        ctx.save_for_backward(x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dx = new_act(N, Cc, H, W, x.dtype, x.device)
+        L.check(L.load().mt_bce_const_bwd(_mt(x.dtype), _ptr(x), ctx.t, _ptr(_gs(g)), _ptr(dx), N * H * W, Cc,
+                                          padc(Cc), _stream()), "mt_bce_const_bwd")
+        return dx, None
+
+
+def bce_logits_const(x, target_is_real):
+    """nn.BCEWithLogitsLoss()(x, ones/zeros expanded) -- GANLoss 'vanilla' (loss.py:58-63)"""
+    return _BceConst.apply(x, 1.0 if target_is_real else 0.0)
+
+
+class _BceTarget(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = _f32c(x), _f32c(t)
+        if x.shape != t.shape:
+            raise RuntimeError(f"bce: shape mismatch {tuple(x.shape)} vs {tuple(t.shape)}")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_bce_target_fwd(_ptr(x), _ptr(t), _ptr(loss), x.numel(), _stream()), "mt_bce_target_fwd")
+        ctx.save_for_backward(x, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.check(L.load().mt_bce_target_bwd(_ptr(x), _ptr(t), _ptr(_gs(g)), _ptr(dx), x.numel(), _stream()),
+                "mt_bce_target_bwd")
+        return dx, None
+
+
+def bce_logits(x, target):
+    """nn.BCEWithLogitsLoss()(x, target) on fp32 [N, D] class logits"""
+    return _BceTarget.apply(x, target)
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.dim() == 4:
+            a, b = canon(a), canon(b)
+            n, cnt, mt = _numel_padded(a), a.numel(), _mt(a.dtype)
+        else:
+            a, b = _f32c(a), _f32c(b)
+            n, cnt, mt = a.numel(), a.numel(), L.MT_F32
+        if a.shape != b.shape:
+            raise RuntimeError(f"l1: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        L.check(L.load().mt_l1_fwd(mt, _ptr(a), _ptr(b), _ptr(loss), n, cnt, _stream()), "mt_l1_fwd")
+        ctx.cfg = (n, cnt, mt)
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        n, cnt, mt = ctx.cfg
+
+        def like(t):
+            return new_act(*t.shape, t.dtype, t.device) if t.dim() == 4 else torch.empty_like(t)
+        da = like(a) if ctx.needs_input_grad[0] else None
+        db = like(b) if ctx.needs_input_grad[1] else None
+        L.check(L.load().mt_l1_bwd(mt, _ptr(a), _ptr(b), _ptr(_gs(g)), _ptr(da), _ptr(db), n, cnt, _stream()),
+                "mt_l1_bwd")
+        return da, db
+
+
+def l1_loss(a, b):
+    """nn.L1Loss()(a, b) (mean)"""
+    return _L1.apply(a, b)
+
+
+class _L2Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = canon(x)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_l2mean_fwd(_mt(x.dtype), _ptr(x), _ptr(loss), _numel_padded(x), x.numel(), _stream()),
+                "mt_l2mean_fwd")
+        ctx.save_for_backward(x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = new_act(*x.shape, x.dtype, x.device)
+        L.check(L.load().mt_l2mean_bwd(_mt(x.dtype), _ptr(x), _ptr(_gs(g)), _ptr(dx), _numel_padded(x), x.numel(),
+                                       _stream()), "mt_l2mean_bwd")
+        return dx
+
+
+def l2_mean(x):
+    """torch.mean(torch.pow(x, 2)) (adain_model.py:396-399)"""
+    return _L2Mean.apply(x)
+
+
+class _Reparam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _f32c(mu), _f32c(logvar), _f32c(eps)
+        z = torch.empty_like(mu)
+        L.check(L.load().mt_reparam_fwd(_ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream()),
+                "mt_reparam_fwd")
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = _f32c(dz)
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        L.check(L.load().mt_reparam_bwd(_ptr(logvar), _ptr(eps), _ptr(dz), _ptr(dmu), _ptr(dlv), dz.numel(),
+                                        _stream()), "mt_reparam_bwd")
+        return dmu, dlv, None
+
+
+def reparameterize(mu, logvar, eps):
+    """eps * exp(0.5*logvar) + mu (networks.py:130-135)"""
+    return _Reparam.apply(mu, logvar, eps)
+
+
+class _KL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _f32c(mu), _f32c(logvar)
+        kl = torch.empty((), dtype=torch.float32, device=mu.device)
+        L.check(L.load().mt_kl_fwd(_ptr(mu), _ptr(logvar), _ptr(kl), mu.numel(), _stream()), "mt_kl_fwd")
+        ctx.save_for_backward(mu, logvar)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        L.check(L.load().mt_kl_bwd(_ptr(mu), _ptr(logvar), _ptr(_gs(g)), _ptr(dmu), _ptr(dlv), mu.numel(), _stream()),
+                "mt_kl_bwd")
+        return dmu, dlv
+
+
+def kl_sum(mu, logvar):
+    """-0.5 * sum(1 + logvar - mu^2 - exp(logvar)) (adain_model.py:313-314)"""
+    return _KL.apply(mu, logvar)
+
+
+# --------------------------------------------------------------------------------------
+# optimizer step
+# --------------------------------------------------------------------------------------
+def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, wd, step):
+    """One fused launch updating every tensor of an optimizer (torch.optim.Adam semantics)."""
+    if not params:
+        return
+    dev = params[0].device
+    ptrs, sizes = [], []
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        for t in (p, g, m, v):
+            _need_hip(t)
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("adam_multi needs contiguous fp32 tensors")
+        ptrs += [p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()]
+        sizes.append(p.numel())
+    tp = torch.tensor(ptrs, dtype=torch.int64).to(dev, non_blocking=False)
+    ts = torch.tensor(sizes, dtype=torch.int64).to(dev, non_blocking=False)
+    L.check(L.load().mt_adam_multi(_ptr(tp), _ptr(ts), len(sizes), max(sizes), lr, beta1, beta2, eps, wd, step,
+                                   _stream()), "mt_adam_multi")
+    bump_epoch(params)
+
+
+@contextlib.contextmanager
+def frozen(*modules):
+    """Temporarily mark the parameters of ``modules`` as not requiring grad (their weight
+    gradients are computed-and-discarded by the reference; skipping them is trajectory
+    identical -- SURVEY.md Appendix C)."""
+    ps = [p for m in modules for p in m.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)

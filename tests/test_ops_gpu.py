@@ -1,0 +1,346 @@
+"""GPU parity of every HIP op against a plain PyTorch fp32 CPU reference of the same op
+(forward and all gradients).  fp32 path: tight tolerance; bf16 path: bf16-rounding tolerance."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-5), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+
+
+def _ops(dtype):
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(dtype)
+    return ops
+
+
+def _close(a, b, dtype, scale=1.0, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    tol = TOL[dtype]
+    ref = b.abs().max().item() + 1e-12
+    if dtype == torch.bfloat16:
+        # bf16 storage: inputs/outputs carry 2^-9 relative rounding, and a ReLU mask can flip
+        # where the pre-activation is within rounding of 0 -- judge by relative L2 error.
+        num = (a - b).norm().item()
+        den = b.norm().item() + 1e-12
+        assert num <= 2e-2 * scale * den + 1e-3, f"{what}: rel L2 err {num / den:.3e}"
+        return
+    err = (a - b).abs().max().item()
+    assert err <= tol["atol"] * scale * max(ref, 1.0) + tol["rtol"] * ref, f"{what}: max err {err:.3e}, ref max {ref:.3e}"
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # name, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act
+    ("k3s1_reflect", 2, 16, 12, 12, 16, 3, 1, 1, "reflect", False, None),
+    ("k7s1_reflect_stem", 2, 3, 16, 16, 8, 7, 1, 3, "reflect", True, None),
+    ("k3s2_reflect", 2, 8, 16, 16, 16, 3, 2, 1, "reflect", True, "lrelu"),
+    ("k3s2_reflect_odd", 1, 8, 15, 13, 16, 3, 2, 1, "reflect", True, None),
+    ("k4s2_reflect_es", 2, 5, 16, 16, 8, 4, 2, 1, "reflect", True, None),
+    ("k4s2_zero_msd", 2, 8, 16, 16, 16, 4, 2, 1, "zero", False, "lrelu"),
+    ("k1_pad1_patch", 2, 16, 4, 4, 1, 1, 1, 1, "zero", False, None),
+    ("k4_valid_cls", 2, 16, 4, 4, 2, 4, 1, 0, "zero", False, None),
+    ("k1_shortcut", 2, 8, 8, 8, 16, 1, 1, 0, "zero", True, None),
+    ("k7s2_reflect_dc", 1, 8, 20, 20, 8, 7, 2, 1, "reflect", True, None),
+    ("k3s1_wide", 2, 64, 20, 20, 160, 3, 1, 1, "reflect", False, "relu"),
+    ("k3s1_256", 1, 256, 16, 16, 256, 3, 1, 1, "reflect", False, None),
+    ("k3s2_zero_odd", 1, 24, 9, 11, 40, 3, 2, 1, "zero", True, None),
+]
+
+
+def _ref_conv(x, w, b, stride, pad, pad_mode, act):
+    if pad_mode == "reflect" and pad > 0:
+        x = F.pad(x, (pad,) * 4, mode="reflect")
+        pad = 0
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if act == "lrelu":
+        y = F.leaky_relu(y, 0.01)
+    elif act == "relu":
+        y = F.relu(y)
+    elif act == "tanh":
+        y = torch.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(case, dtype, hip_device):
+    ops = _ops(dtype)
+    name, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
+    x = _rnd(N, Ci, H, W, seed=1)
+    w = _rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = _rnd(Co, seed=3, scale=0.1) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = _ref_conv(xr, wr, br, stride, pad, pad_mode, act)
+    gy = _rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+
+    xd = x.to(hip_device).requires_grad_()
+    wd = w.to(hip_device).requires_grad_()
+    bd = b.to(hip_device).requires_grad_() if bias else None
+    y = ops.conv2d(xd, wd, bd, stride=stride, pad=pad, pad_mode=pad_mode, act=act)
+    assert ops.is_canonical(y)
+    _close(y, yr, dtype, what=f"{name} fwd")
+    y.backward(gy.to(hip_device))
+    _close(xd.grad, xr.grad, dtype, what=f"{name} dx")
+    _close(wd.grad, wr.grad, dtype, what=f"{name} dw", scale=4.0)
+    if bias:
+        _close(bd.grad, br.grad, dtype, what=f"{name} db", scale=4.0)
+
+
+CONVT_CASES = [
+    ("k3s2p1op1", 2, 16, 8, 8, 8, 3, 2, 1, 1, True, None),
+    ("k3s2p1op1_odd", 1, 8, 5, 7, 16, 3, 2, 1, 1, True, None),
+    ("k1s1_tanh_rgb", 2, 8, 12, 12, 3, 1, 1, 0, 0, False, "tanh"),
+    ("k3s2_wide", 1, 128, 10, 10, 64, 3, 2, 1, 1, True, None),
+    ("k4s2p1", 1, 8, 6, 6, 8, 4, 2, 1, 0, False, None),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_conv_transpose2d(case, dtype, hip_device):
+    ops = _ops(dtype)
+    name, N, Ci, H, W, Co, k, stride, pad, op, bias, act = case
+    x = _rnd(N, Ci, H, W, seed=1)
+    w = _rnd(Ci, Co, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = _rnd(Co, seed=3, scale=0.1) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = F.conv_transpose2d(xr, wr, br, stride=stride, padding=pad, output_padding=op)
+    if act == "tanh":
+        yr = torch.tanh(yr)
+    gy = _rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd = x.to(hip_device).requires_grad_()
+    wd = w.to(hip_device).requires_grad_()
+    bd = b.to(hip_device).requires_grad_() if bias else None
+    y = ops.conv_transpose2d(xd, wd, bd, stride=stride, pad=pad, out_pad=op, act=act)
+    _close(y, yr, dtype, what=f"{name} fwd")
+    y.backward(gy.to(hip_device))
+    _close(xd.grad, xr.grad, dtype, what=f"{name} dx")
+    _close(wd.grad, wr.grad, dtype, what=f"{name} dw", scale=4.0)
+    if bias:
+        _close(bd.grad, br.grad, dtype, what=f"{name} db", scale=4.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear(dtype, hip_device):
+    ops = _ops(dtype)
+    x, w, b = _rnd(6, 12, seed=1), _rnd(256, 12, seed=2), _rnd(256, seed=3)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    gy = _rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(hip_device).requires_grad_() for t in (x, w, b))
+    y = ops.linear(xd, wd, bd)
+    _close(y, yr, torch.float32, what="linear fwd")
+    y.backward(gy.to(hip_device))
+    _close(xd.grad, xr.grad, torch.float32, what="linear dx")
+    _close(wd.grad, wr.grad, torch.float32, what="linear dw")
+    _close(bd.grad, br.grad, torch.float32, what="linear db")
+
+
+def _ref_ln(x, g, b):
+    shp = x.shape[1:]
+    return F.layer_norm(x, shp, g.expand(shp), b.expand(shp))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["instance_relu", "instance_lrelu_res", "adain_relu", "adain_res", "layer_relu"])
+@pytest.mark.parametrize("shape", [(2, 16, 12, 12), (3, 8, 5, 7), (2, 64, 33, 31)])
+def test_norms(mode, shape, dtype, hip_device):
+    ops = _ops(dtype)
+    N, Cc, H, W = shape
+    x = _rnd(*shape, seed=1) * 1.5 + 0.3
+    res = _rnd(*shape, seed=5)
+    gb = _rnd(N, 2 * Cc, seed=6, scale=0.5)
+    gamma = (1.0 + _rnd(Cc, 1, 1, seed=7, scale=0.3))
+    beta = _rnd(Cc, 1, 1, seed=8, scale=0.3)
+    xr = x.clone().requires_grad_()
+    resr, gbr, gr, btr = (t.clone().requires_grad_() for t in (res, gb, gamma, beta))
+    xd = x.to(hip_device).requires_grad_()
+    resd, gbd, gd, btd = (t.to(hip_device).requires_grad_() for t in (res, gb, gamma, beta))
+    extra = []
+    if mode == "instance_relu":
+        yr = F.relu(F.instance_norm(xr))
+        y = ops.instance_norm_act(xd, act="relu")
+    elif mode == "instance_lrelu_res":
+        yr = F.leaky_relu(F.instance_norm(xr), 0.01) + resr
+        y = ops.instance_norm_act(xd, act="lrelu", res=resd)
+        extra = [(resd, resr, "dres")]
+    elif mode in ("adain_relu", "adain_res"):
+        wgt, bias = torch.chunk(gbr.view(N, 2 * Cc, 1, 1), 2, dim=1)
+        yr = (1 + wgt) * F.instance_norm(xr) + bias
+        if mode == "adain_relu":
+            yr = F.relu(yr)
+            y = ops.adain_act(xd, gbd, act="relu")
+        else:
+            yr = yr + resr
+            y = ops.adain_act(xd, gbd, res=resd)
+            extra = [(resd, resr, "dres")]
+        extra.append((gbd, gbr, "dgb"))
+    else:
+        yr = F.relu(_ref_ln(xr, gr, btr))
+        y = ops.layer_norm_act(xd, gd, btd, act="relu")
+        extra = [(gd, gr, "dgamma"), (btd, btr, "dbeta")]
+    gy = _rnd(*shape, seed=9)
+    yr.backward(gy)
+    y.backward(gy.to(hip_device))
+    _close(y, yr, dtype, what=f"{mode} fwd")
+    _close(xd.grad, xr.grad, dtype, what=f"{mode} dx", scale=2.0)
+    for a, b, nm in extra:
+        sc = 8.0 if nm in ("dgb", "dgamma", "dbeta") else 1.0
+        _close(a.grad, b.grad, dtype, what=f"{mode} {nm}", scale=sc)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_elementwise_and_pools(dtype, hip_device):
+    ops = _ops(dtype)
+    x = _rnd(2, 16, 10, 12, seed=1)
+    for name, fn_ref, fn in [
+        ("lrelu", lambda t: F.leaky_relu(t, 0.01), lambda t: ops.activation(t, "lrelu")),
+        ("relu", F.relu, lambda t: ops.activation(t, "relu")),
+        ("tanh", torch.tanh, lambda t: ops.activation(t, "tanh")),
+        ("pool2", lambda t: F.avg_pool2d(t, 2, 2), ops.avg_pool2),
+        ("pool3s2", lambda t: F.avg_pool2d(t, 3, 2, 1, count_include_pad=False), ops.avg_pool3s2),
+        ("gap", lambda t: F.adaptive_avg_pool2d(t, 1).flatten(1), ops.global_avg_pool),
+        ("add", lambda t: t + t * 0.5, lambda t: ops.add(t, ops.canon(t.detach() * 0.5))),
+    ]:
+        xr = x.clone().requires_grad_()
+        xd = x.to(hip_device).requires_grad_()
+        yr, y = fn_ref(xr), fn(xd)
+        gy = _rnd(*yr.shape, seed=2)
+        yr.backward(gy)
+        y.backward(gy.to(hip_device))
+        _close(y, yr, dtype, what=f"{name} fwd")
+        ref_grad = xr.grad if name != "add" else gy  # the 0.5*t branch is detached on the device side
+        _close(xd.grad, ref_grad, dtype, what=f"{name} dx")
+    # odd sizes for the 3x3/s2 pool (pyramid of the multi-scale discriminator)
+    x = _rnd(1, 3, 9, 7, seed=3)
+    xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+    yr, y = F.avg_pool2d(xr, 3, 2, 1, count_include_pad=False), ops.avg_pool3s2(xd)
+    gy = _rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    y.backward(gy.to(hip_device))
+    _close(y, yr, dtype, what="pool3s2 odd fwd")
+    _close(xd.grad, xr.grad, dtype, what="pool3s2 odd dx")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_cat_noise(dtype, hip_device):
+    ops = _ops(dtype)
+    x = _rnd(3, 3, 8, 6, seed=1)
+    xd = x.to(hip_device)
+    c = ops.canon(xd)
+    assert ops.is_canonical(c) and c.shape == x.shape
+    _close(ops.to_nchw_f32(c), x, dtype, what="roundtrip")
+    # channels_last and sliced sources
+    _close(ops.to_nchw_f32(ops.canon(xd.contiguous(memory_format=torch.channels_last))), x, dtype, what="cl")
+    big = _rnd(3, 7, 8, 6, seed=2).to(hip_device)
+    _close(ops.to_nchw_f32(ops.canon(big[:, 2:5])), big[:, 2:5].cpu(), dtype, what="slice")
+    # class planes
+    cls = torch.eye(4)[[1, 3, 0]]
+    xr = x.clone().requires_grad_()
+    ref = torch.cat([xr, cls.view(3, 4, 1, 1).repeat(1, 1, 8, 6)], dim=1)
+    xg = xd.clone().requires_grad_()
+    out = ops.cat_class_planes(xg, cls.to(hip_device))
+    _close(out, ref, dtype, what="cat_class")
+    gy = _rnd(*ref.shape, seed=3)
+    ref.backward(gy)
+    out.backward(gy.to(hip_device))
+    _close(xg.grad, xr.grad, dtype, what="cat_class dimg")
+    # batch cat keeps layout
+    a, b = ops.canon(xd[:1]), ops.canon(xd[1:])
+    cb = ops.cat_batch([a, b])
+    assert ops.is_canonical(cb)
+    _close(cb, x, dtype, what="cat_batch")
+    # device noise: N(0,1) moments, deterministic in (seed, offset)
+    z = torch.zeros(4, 64, 32, 32, device=hip_device)
+    n1 = ops.to_nchw_f32(ops.gaussian_noise_add(z, 1234, 0))
+    n2 = ops.to_nchw_f32(ops.gaussian_noise_add(z, 1234, 0))
+    n3 = ops.to_nchw_f32(ops.gaussian_noise_add(z, 1235, 0))
+    assert torch.equal(n1, n2) and not torch.equal(n1, n3)
+    assert abs(n1.mean().item()) < 0.01 and abs(n1.std().item() - 1.0) < 0.01
+    assert abs((n1 ** 4).mean().item() - 3.0) < 0.1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_losses(dtype, hip_device):
+    ops = _ops(dtype)
+    # patch logits with 1 logical channel (pad channels must not count)
+    x = _rnd(4, 1, 6, 6, seed=1)
+    for real in (True, False):
+        xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+        t = torch.ones_like(x) if real else torch.zeros_like(x)
+        lr = F.binary_cross_entropy_with_logits(xr, t)
+        l = ops.bce_logits_const(xd, real)
+        (lr * 3).backward()
+        (l * 3).backward()
+        _close(l, lr, dtype, what="bce_const")
+        _close(xd.grad, xr.grad, dtype, what="bce_const dx")
+    p, t = _rnd(6, 4, seed=2), torch.eye(4)[[0, 1, 2, 3, 1, 2]]
+    pr, pd = p.clone().requires_grad_(), p.to(hip_device).requires_grad_()
+    lr, l = F.binary_cross_entropy_with_logits(pr, t), ops.bce_logits(pd, t.to(hip_device))
+    lr.backward()
+    l.backward()
+    _close(l, lr, torch.float32, what="bce_target")
+    _close(pd.grad, pr.grad, torch.float32, what="bce_target dx")
+    a, b = _rnd(2, 3, 16, 16, seed=3), _rnd(2, 3, 16, 16, seed=4)
+    ar, ad = a.clone().requires_grad_(), a.to(hip_device).requires_grad_()
+    lr, l = F.l1_loss(b, ar) * 10, ops.l1_loss(b.to(hip_device), ad) * 10
+    lr.backward()
+    l.backward()
+    _close(l, lr, dtype, what="l1")
+    _close(ad.grad, ar.grad, dtype, what="l1 dx")
+    z = _rnd(2, 16, 8, 8, seed=5)
+    zr, zd = z.clone().requires_grad_(), z.to(hip_device).requires_grad_()
+    lr, l = torch.mean(torch.pow(zr, 2)) * 0.01, ops.l2_mean(zd) * 0.01
+    lr.backward()
+    l.backward()
+    _close(l, lr, dtype, what="l2mean")
+    _close(zd.grad, zr.grad, dtype, what="l2mean dx")
+    mu, lv, eps = _rnd(4, 8, seed=6), _rnd(4, 8, seed=7) * 0.3, _rnd(4, 8, seed=8)
+    mr, lvr = mu.clone().requires_grad_(), lv.clone().requires_grad_()
+    md, lvd = mu.to(hip_device).requires_grad_(), lv.to(hip_device).requires_grad_()
+    zr = eps * torch.exp(0.5 * lvr) + mr
+    klr = torch.sum(1 + lvr - mr.pow(2) - lvr.exp()) * -0.5 * 0.01
+    z_ = ops.reparameterize(md, lvd, eps.to(hip_device))
+    kl = ops.kl_sum(md, lvd) * 0.01
+    g = _rnd(4, 8, seed=9)
+    (zr * g).sum().add(klr).backward()
+    ((z_ * g.to(hip_device)).sum() + kl).backward()
+    _close(z_, zr, torch.float32, what="reparam")
+    _close(kl, klr, torch.float32, what="kl")
+    _close(md.grad, mr.grad, torch.float32, what="dmu")
+    _close(lvd.grad, lvr.grad, torch.float32, what="dlogvar")
+    l1r = F.l1_loss(mr[:2], eps[:2])
+    l1 = ops.l1_loss(md[:2], eps[:2].to(hip_device))
+    _close(l1, l1r, torch.float32, what="l1 2d")
+
+
+def test_adam_multi(hip_device):
+    from masterthesis_amd import hip_ops as ops
+    torch.manual_seed(0)
+    ps = [torch.randn(s) for s in [(16, 3, 3, 3), (7,), (1000, 33)]]
+    ref = [p.clone().requires_grad_() for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    dev = [p.to(hip_device) for p in ps]
+    ms = [torch.zeros_like(p) for p in dev]
+    vs = [torch.zeros_like(p) for p in dev]
+    for step in range(1, 4):
+        gs = [torch.randn_like(p) for p in ps]
+        for r, g in zip(ref, gs):
+            r.grad = g.clone()
+        opt.step()
+        ops.adam_multi(dev, [g.to(hip_device) for g in gs], ms, vs, 1e-3, 0.5, 0.999, 1e-8, 1e-4, step)
+    for d, r in zip(dev, ref):
+        _close(d, r, torch.float32, what="adam")
