@@ -1,0 +1,246 @@
+"""ORACLE tooling -- generates tests/golden/*.npz by IMPORTING the reference (read-only at
+/root/reference) in this container and running it on the CPU.  No-op when the reference is absent
+(GPU box).  Nothing of the reference's source is copied; fixtures hold inputs, recorded random
+draws and outputs only.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+Import recipe: stub modules for tensorboardX / torchvision / cv2
+(none carries hot-path arithmetic), `Tensor.get_device` shim so the reference's GaussianNoiseLayer
+and GANLoss run on CPU tensors (misc.py:25, loss.py:60,62), args as a Namespace.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _install_stubs():
+    sys.dont_write_bytecode = True
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Writer:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+    mod("tensorboardX", SummaryWriter=_Writer)
+    tv = mod("torchvision")
+    tv.utils = mod("torchvision.utils", save_image=lambda *a, **k: None)
+    tv.transforms = mod("torchvision.transforms")
+    tv.models = mod("torchvision.models")
+    tv.models.vgg = mod("torchvision.models.vgg")
+    mod("cv2")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    orig = torch.Tensor.get_device
+
+    def get_device(self):
+        return self.device if not self.is_cuda else orig(self)
+    torch.Tensor.get_device = get_device
+
+
+def ref_args(**kw):
+    a = dict(mode="train", logdir="/tmp/_mt_golden_logs", input_dim=3, output_dim=3, dim=8, init_type="normal",
+             init_gain=0.02, num_domains=2, latent_dim=8, up_type="transpose", dec_norm="layer", enc_norm="instance",
+             use_dropout=False, batch_size=1, crop_size=64, resume=None, resume_opt=None, gpu_ids=[], dis_norm=None,
+             dis_sn=False, ms_dis=False, num_scales=3, use_dis_content=False, lr=1e-4, wd=1e-4, beta1=0.5,
+             beta2=0.999, lr_policy="step", n_iters=1000000, n_iter_decay=600000, last_iter=-1, d_iter=3,
+             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, lambda_style=5.0, lambda_perceptual=1.0,
+             gan_mode="vanilla", use_ragan=False, vgg_loss=None, checkpoint_dir="/tmp", display_dir="/tmp",
+             concat=False, reparam=False, max_iter=1000000)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+@contextlib.contextmanager
+def record_rng(log):
+    """Record every tensor drawn through torch.randn / Tensor.normal_ (the reference's only draws
+    inside a step: misc.py:25, networks.py:132, adain_model.py:84)."""
+    o_randn, o_normal = torch.randn, torch.Tensor.normal_
+
+    def randn(*a, **k):
+        t = o_randn(*a, **k)
+        log.append(t.detach().clone().numpy())
+        return t
+
+    def normal_(self, *a, **k):
+        t = o_normal(self, *a, **k)
+        log.append(t.detach().clone().numpy())
+        return t
+    torch.randn, torch.Tensor.normal_ = randn, normal_
+    try:
+        yield
+    finally:
+        torch.randn, torch.Tensor.normal_ = o_randn, o_normal
+
+
+def make_batch(B, D, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    x2 = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    d1 = torch.randint(0, D, (B,), generator=g)
+    d2 = (d1 + 1 + torch.randint(0, D - 1, (B,), generator=g)) % D
+    eye = torch.eye(D)
+    return {"x1": x1, "x2": x2, "y1": eye[d1], "y2": eye[d2]}
+
+
+def _flat(prefix, sd, out):
+    for k, v in sd.items():
+        out[f"{prefix}/{k}"] = v.detach().cpu().clone().numpy()
+
+
+def checksum(t):
+    """[sum, sum|x|, sum x^2] in float64 -- compact pin for tensors too large to commit."""
+    t = torch.as_tensor(t).double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def _flat_sums(prefix, sd, out):
+    for k, v in sd.items():
+        out[f"{prefix}/{k}"] = checksum(v.detach())
+
+
+def step_case(name, model_name, steps=2, seed=0, full_grads=(0,), **kw):
+    """One or two full optimize_parameters() calls of the imported reference."""
+    import models  # the reference package
+    args = ref_args(**kw)
+    torch.manual_seed(seed)
+    M = getattr(models, model_name)(args)
+    M.initialize()
+    # nn.Linear layers keep torch's default init (functions.py:72-94 only touches Conv*)
+    out = {}
+    for net in M.model:
+        _flat(f"init/{net}", M.model[net].state_dict(), out)
+    batch = make_batch(args.batch_size, args.num_domains, args.crop_size, args.crop_size, seed + 100)
+    for k, v in batch.items():
+        out[f"batch/{k}"] = v.numpy()
+    # grads as consumed by each optimizer.step() (7 per full step), in call order
+    grads = []
+    for net, opt in M.optimizer.items():
+        o_step = opt.step
+
+        def step(closure=None, _net=net, _o=o_step):
+            grads.append((_net, {k: (p.grad.detach().clone() if p.grad is not None else None)
+                                 for k, p in M.model[_net].named_parameters()}))
+            return _o()
+        opt.step = step
+    meta = {"name": name, "model": model_name, "args": {k: v for k, v in vars(args).items()
+                                                        if isinstance(v, (int, float, str, bool, type(None)))},
+            "steps": steps, "losses": [], "rng_counts": [], "grad_nets": []}
+    for it in range(steps):
+        rng = []
+        grads.clear()
+        with record_rng(rng):
+            M.update_lr()
+            M.set_inputs(batch)
+            M.optimize_parameters(it)
+        for i, t in enumerate(rng):
+            out[f"rng/{it}/{i}"] = t
+        meta["rng_counts"].append(len(rng))
+        meta["losses"].append({k: float(v) for k, v in M.loss.items()})
+        nets_called = []
+        for j, (net, g) in enumerate(grads):
+            nets_called.append(net)
+            for k, v in g.items():
+                if v is not None:
+                    if it in full_grads:
+                        out[f"grad/{it}/{j}/{net}/{k}"] = v.numpy()
+                    else:
+                        out[f"gradsum/{it}/{j}/{net}/{k}"] = checksum(v)
+        meta["grad_nets"].append(nets_called)
+        for net in M.model:
+            _flat_sums(f"aftersum/{it}/{net}", M.model[net].state_dict(), out)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, losses[0]={meta['losses'][0]}")
+
+
+def nets_case(name="nets_forward", seed=3):
+    """Forward outputs of every network class on the path (eval mode: no noise; eps recorded)."""
+    from models.core import networks as N
+    from models.core.functions import init_weights
+    torch.manual_seed(seed)
+    out, meta = {}, {"name": name, "cases": []}
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    def add(tag, net, inputs, fwd):
+        init_weights(net, "normal", 0.02)
+        net.eval()
+        _flat(f"{tag}/P", net.state_dict(), out)
+        for k, v in inputs.items():
+            out[f"{tag}/in/{k}"] = v.numpy()
+        rng = []
+        with torch.no_grad(), record_rng(rng):
+            res = fwd(net)
+        res = res if isinstance(res, (tuple, list)) else (res,)
+        flat = []
+        for r in res:
+            flat += list(r) if isinstance(r, (tuple, list)) else [r]
+        for i, r in enumerate(flat):
+            out[f"{tag}/out/{i}"] = r.numpy()
+        for i, t in enumerate(rng):
+            out[f"{tag}/rng/{i}"] = t
+        meta["cases"].append({"tag": tag, "n_out": len(flat), "n_rng": len(rng)})
+
+    x = rnd(2, 3, 64, 64)
+    c = torch.eye(4)[[1, 3]]
+    z = rnd(2, 8)
+    add("Ec", N.ContentEncoder(3, dim=8), {"x": x}, lambda n: n(x))
+    add("Es", N.ReparameterizedStyleEncoder(3, output_dim=8, dim=8, num_domains=4, norm_layer=None,
+                                            activation="lrelu"), {"x": x, "c": c}, lambda n: n(x, c))
+    zc = rnd(2, 32, 16, 16)
+    add("AdaINDec", N.AdaINDecoder(3, dim=32, num_domains=4, latent_dim=8), {"x": zc, "z": z, "c": c},
+        lambda n: n(zc, z, c))
+    add("D", N.Discriminator(3, dim=8, num_domains=4, image_size=64), {"x": x}, lambda n: n(x))
+    x256 = rnd(1, 3, 256, 256)
+    add("MsD", N.MultiScaleDiscriminator(3, dim=2, num_domains=4), {"x": x256}, lambda n: n(x256))
+    zc56 = rnd(2, 8, 56, 56)
+    add("Dc", N.ContentDiscriminator(dim=8, num_domains=4), {"x": zc56}, lambda n: n(zc56))
+    add("EsPlain", N.StyleEncoder(3, output_dim=8, dim=8, num_domains=4, activation="lrelu"), {"x": x, "c": c},
+        lambda n: n(x, c))
+    zc2 = rnd(2, 32, 16, 16)
+    add("DecConcat", N.DecoderConcat(3, dim=32, num_domains=4, latent_dim=8), {"x": zc2, "z": z, "c": c},
+        lambda n: n(zc2, z, c))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present -- nothing to generate")
+        return 0
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    torch.set_num_threads(4)
+    nets_case()
+    step_case("adain_step_d2", "AdaINModel", steps=2, seed=0, num_domains=2, batch_size=1)
+    # dim 4: channel counts that are not multiples of 8 (exercises the channel padding)
+    step_case("adain_step_d4_b2", "AdaINModel", steps=1, seed=1, num_domains=4, batch_size=2, dim=4)
+    step_case("base_step_concat_reparam", "BaseModel", steps=1, seed=2, num_domains=2, batch_size=1, dim=4,
+              concat=True, reparam=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
