@@ -1,0 +1,83 @@
+"""Data parallelism for the step: one process per GPU, gradient exchange over RCCL/xGMI.
+
+The reference's only multi-GPU hook is single-process ``nn.DataParallel`` (functions.py:98-101).  Here
+every rank owns ``batch_size`` pairs and a full replica; after each of the four backward phases the
+flat gradient buffer of every network that is about to be stepped is all-reduced (mean) on a side
+HIP stream, bucket by bucket, so the exchange of network k overlaps the Adam launch of network k-1
+and, for the discriminator phases, the generator work that follows.  SURVEY.md section 8(e).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """All-reduce (mean) of flat gradient buffers, asynchronously on a side stream when on GPU.
+
+    ``reduce(buffers)`` enqueues one collective per buffer and returns handles; ``wait(handle)`` makes
+    the current stream wait for that buffer only.  Works with any backend (gloo on CPU for tests)."""
+
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.side = None
+
+    def reduce(self, buffers):
+        handles = []
+        if not self.enabled:
+            return [None for _ in buffers]
+        on_gpu = buffers and buffers[0].is_cuda
+        if on_gpu:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())      # grads were produced on the compute stream
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                for b in buffers:
+                    b.mul_(1.0 / self.world)
+                    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    b.record_stream(self.side)
+                    handles.append(ev)
+        else:
+            for b in buffers:
+                b.mul_(1.0 / self.world)
+                handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return handles
+
+    @staticmethod
+    def wait(handle):
+        if handle is None:
+            return
+        if isinstance(handle, torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(handle)
+        else:
+            handle.wait()
+
+
+def broadcast_parameters(tensors, src=0, group=None):
+    """Make every replica start from rank ``src``'s weights."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=group)

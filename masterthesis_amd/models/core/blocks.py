@@ -1,0 +1,201 @@
+"""Composite blocks -- same class names, constructor signatures and state_dict keys as the reference's
+``src/models/core/blocks.py`` (ConvBlock 10-46, UpsampleBlock 48-91, DownResnetBlock 93-119, ResnetBlock
+121-138, AdaINResnetBlock 140-167, DecResnetBlock 169-208), but each block executes as a short chain of
+fused HIP kernels: reflection padding lives inside the conv's gather, bias + activation in its epilogue,
+normalisation + activation (+ the residual add) in one elementwise pass.
+
+``nn.Conv2d`` / ``nn.ConvTranspose2d`` / ``nn.Linear`` objects are used purely as parameter holders (so
+initialisation and checkpoint keys are the reference's); their own forward is never called.
+"""
+import torch
+import torch.nn as nn
+
+from ... import hip_ops as ops
+from .functions import get_activation_layer, get_norm_layer, get_padding_layer, spectral_norm
+from .norm import AdaptiveInstanceNorm, LayerNorm
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder keeping the reference's nn.Sequential indices (pad / norm / act / pool)."""
+
+    def __init__(self, kind, arg=None):
+        super().__init__()
+        self.kind, self.arg = kind, arg
+
+    def extra_repr(self):
+        return f"{self.kind}({self.arg})" if self.arg is not None else self.kind
+
+
+def _make_norm(name, dim):
+    if name == "layer":
+        return LayerNorm(dim)
+    if name == "instance":
+        return _Marker("instance_norm", dim)
+    raise NotImplementedError(f"norm '{name}' cannot be used inside a block")
+
+
+class ConvBlock(nn.Module):
+    """pad -> conv -> norm -> activation (reference blocks.py:10-46)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride=1, padding=0, bias=False, norm_layer=None,
+                 activation=None, padding_type=None, sn=False):
+        super().__init__()
+        self.pad_mode = "reflect" if get_padding_layer(padding_type) else "zero"
+        self.act = get_activation_layer(activation)
+        self.norm = get_norm_layer(norm_layer)
+        self.stride, self.padding = stride, padding
+        if sn:
+            spectral_norm(None)
+        mods = []
+        if self.pad_mode == "reflect":
+            mods.append(_Marker("reflection_pad", padding))
+        self._ci = len(mods)
+        # padding of the holder is 0 when a pad layer precedes it, exactly like the reference
+        mods.append(nn.Conv2d(input_dim, output_dim, kernel_size, stride, 0 if self.pad_mode == "reflect" else padding,
+                              bias=bias))
+        self._ni = None
+        if self.norm is not None:
+            self._ni = len(mods)
+            mods.append(_make_norm(self.norm, output_dim))
+        if self.act is not None:
+            mods.append(_Marker(self.act))
+        self.block = nn.Sequential(*mods)
+
+    def forward(self, x, res=None):
+        conv = self.block[self._ci]
+        fused_act = self.act if self.norm is None else None
+        y = ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
+                       act=fused_act)
+        if self.norm == "instance":
+            return ops.instance_norm_act(y, act=self.act, res=res)
+        if self.norm == "layer":
+            y = self.block[self._ni](y, act=self.act)
+        return y if res is None else ops.add(y, res)
+
+
+class UpsampleBlock(nn.Module):
+    """ConvTranspose2d -> norm -> activation (reference blocks.py:48-91; only up_type 'transpose')."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride=1, padding=0, output_padding=0, bias=False,
+                 norm_layer=None, activation=None, padding_type=None, sn=False, up_type="transpose"):
+        super().__init__()
+        if "transpose" not in up_type:
+            raise NotImplementedError(f"Mode {up_type} is not supported at the moment")
+        if sn:
+            spectral_norm(None)
+        self.act = get_activation_layer(activation)
+        self.norm = get_norm_layer(norm_layer)
+        self.stride, self.padding, self.output_padding = stride, padding, output_padding
+        mods = [nn.ConvTranspose2d(input_dim, output_dim, kernel_size, stride, padding, output_padding, bias=bias)]
+        if self.norm is not None:
+            mods.append(_make_norm(self.norm, output_dim))
+        if self.act is not None:
+            mods.append(_Marker(self.act))
+        self.block = nn.Sequential(*mods)
+
+    def forward(self, x):
+        conv = self.block[0]
+        fused_act = self.act if self.norm is None else None
+        y = ops.conv_transpose2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+                                 out_pad=self.output_padding, act=fused_act)
+        if self.norm == "instance":
+            return ops.instance_norm_act(y, act=self.act)
+        if self.norm == "layer":
+            return self.block[1](y, act=self.act)
+        return y
+
+
+class DownResnetBlock(nn.Module):
+    """reference blocks.py:93-119.  The first layer of ``conv`` is an in-place activation of the block
+    input, so the shortcut branch consumes the ACTIVATED tensor too."""
+
+    def __init__(self, input_dim, output_dim, norm_layer="instance", activation="lrelu", padding_type="reflect",
+                 bias=True):
+        super().__init__()
+        if norm_layer is not None:
+            raise NotImplementedError("DownResnetBlock with a norm layer is not on the hot path (AdaINModel passes None)")
+        self.act = get_activation_layer(activation)
+        self.conv = nn.Sequential(
+            _Marker(self.act),
+            ConvBlock(input_dim, input_dim, 3, 1, padding=1, padding_type=padding_type, norm_layer=None,
+                      activation=activation, bias=bias),
+            ConvBlock(input_dim, output_dim, 3, 1, padding=1, padding_type=padding_type, bias=bias),
+            _Marker("avgpool2"))
+        self.shortcut = nn.Sequential(_Marker("avgpool2"), nn.Conv2d(input_dim, output_dim, 1, 1, 0, bias=bias))
+
+    def forward(self, x):
+        a = ops.activation(x, self.act)
+        h = ops.avg_pool2(self.conv[2](self.conv[1](a)))
+        sc = self.shortcut[1]
+        s = ops.conv2d(ops.avg_pool2(a), sc.weight, sc.bias)
+        return ops.add(h, s)
+
+
+class ResnetBlock(nn.Module):
+    """x + [conv-IN-act, conv-IN](x) (reference blocks.py:121-138); the add rides on the second norm pass."""
+
+    def __init__(self, input_dim, output_dim, dropout=False, norm_layer="instance", padding_type="reflect",
+                 activation="relu"):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("--use_dropout is not implemented (off by default)")
+        self.model = nn.Sequential(
+            ConvBlock(input_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer,
+                      activation=activation),
+            ConvBlock(output_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer))
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), res=x)
+
+
+class AdaINResnetBlock(nn.Module):
+    """conv-AdaIN-act-conv-AdaIN + residual with ONE shared AdaIN projection (reference blocks.py:140-167)."""
+
+    def __init__(self, input_dim, output_dim, dropout=False, style_dim=256, padding_type="reflect", activation="relu"):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("--use_dropout is not implemented (off by default)")
+        self.act = get_activation_layer(activation)
+        self.activation = _Marker(self.act)
+        self.conv1 = ConvBlock(input_dim, output_dim, 3, 1, 1, padding_type=padding_type)
+        self.conv2 = ConvBlock(output_dim, output_dim, 3, 1, 1, padding_type=padding_type)
+        self.norm = AdaptiveInstanceNorm(output_dim, style_dim)
+        self.dropout = nn.Identity()
+
+    def forward(self, x, z):
+        h = self.norm(self.conv1(x), z, act=self.act)
+        return self.norm(self.conv2(h), z, res=x)
+
+
+def _expand_planes(v, ref):
+    return v.view(v.size(0), v.size(1), 1, 1).expand(v.size(0), v.size(1), ref.size(2), ref.size(3))
+
+
+class DecResnetBlock(nn.Module):
+    """BaseModel decoder block (reference blocks.py:169-208); the final add is out of place (the reference's
+    in-place ``out += residual`` on a ReLU output raises under current autograd)."""
+
+    def __init__(self, n_channel, add_channel, norm_layer="instance", padding_type="reflect", stride=1, dropout=False):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("--use_dropout is not implemented (off by default)")
+        self.conv1 = ConvBlock(n_channel, n_channel, 3, stride=stride, padding=1, padding_type=padding_type)
+        self.conv2 = ConvBlock(n_channel, n_channel, 3, stride=stride, padding=1, padding_type=padding_type)
+        self.norm = _Marker("instance_norm", n_channel)
+        nca = n_channel + add_channel
+        self.block1 = nn.Sequential(nn.Conv2d(nca, nca, 1), _Marker("relu"), nn.Conv2d(nca, n_channel, 1), _Marker("relu"))
+        self.block2 = nn.Sequential(nn.Conv2d(nca, nca, 1), _Marker("relu"), nn.Conv2d(nca, n_channel, 1), _Marker("relu"))
+        self.dropout = nn.Identity()
+
+    @staticmethod
+    def _mix(block, t):
+        t = ops.conv2d(t, block[0].weight, block[0].bias, act="relu")
+        return ops.conv2d(t, block[2].weight, block[2].bias, act="relu")
+
+    def forward(self, x, z):
+        ze = _expand_planes(z, x).to(ops.compute_dtype())
+        out = ops.instance_norm_act(self.conv1(x))
+        out = self._mix(self.block1, torch.cat([out, ze], dim=1))
+        out = ops.instance_norm_act(self.conv2(out))
+        out = self._mix(self.block2, torch.cat([out, ze], dim=1))
+        return ops.add(out, x)

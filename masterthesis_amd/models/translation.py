@@ -1,0 +1,284 @@
+"""The G+D training step shared by ``AdaINModel`` and ``BaseModel``.
+
+Reference: src/models/adain_model.py:83-430 and src/models/base_model.py (identical step logic around
+different generator networks).  Same four backward phases and seven Adam steps:
+
+    PHASE 1  D1 on (img, img_fake)      PHASE 2  D2 on (img, img_random)          (update_discriminator)
+    PHASE 3  Ec, Es, Dec  (translation, self/cross-cycle reconstruction, KL)        (backward_generator)
+    PHASE 4  Ec, Dec      (random-style translation, latent regression)             (backward_decoder_random)
+
+MI355X-first execution choices (all trajectory-identical to the reference):
+ * the generator forwards that feed the discriminator update run under ``no_grad`` (the reference builds
+   an autograd graph there and throws it away);
+ * discriminator weight gradients are not computed in the generator phases (the reference computes
+   them and discards them at the next ``zero_grad``);
+ * loss scalars stay on the device; ``.item()``-style host syncs (16 per step in the reference) happen
+   only when the train loop prints / logs;
+ * after each backward the flat gradient buffers of the networks about to be stepped are all-reduced
+   (mean) over RCCL on a side stream; the KL term is a batch SUM in the reference
+   (adain_model.py:313-314) so its gradient is scaled by world_size to stay equal to one process at
+   the global batch.
+"""
+import time
+
+import torch
+
+from .. import hip_ops as ops
+from ..optim import FusedAdam
+from .core import loss as losses
+from .core import networks
+from .core.misc import random_source
+from .model import Model
+
+
+class TranslationModel(Model):
+    """Common constructor tail + step.  Subclasses build content_encoder / style_encoder / decoder."""
+
+    reparam = True
+
+    def _build_training_side(self, args):
+        if "train" not in args.mode:
+            return
+        if args.ms_dis:
+            def make_d():
+                return networks.MultiScaleDiscriminator(args.input_dim, norm_layer=args.dis_norm, sn=args.dis_sn,
+                                                        num_domains=args.num_domains, num_scales=args.num_scales)
+        else:
+            def make_d():
+                return networks.Discriminator(args.input_dim, dim=args.dim, norm_layer=args.dis_norm, sn=args.dis_sn,
+                                              num_domains=args.num_domains, image_size=args.crop_size)
+        self.model.discriminator1 = make_d()
+        self.model.discriminator2 = make_d()
+        for net in self.model:
+            self.optimizer[net] = FusedAdam(self.model[net].parameters(), lr=args.lr,
+                                            betas=(args.beta1, float(args.beta2)), weight_decay=args.wd)
+        if args.use_dis_content:
+            self.model.content_discriminator = networks.ContentDiscriminator(
+                dim=self.model.content_encoder.output_dim, num_domains=args.num_domains)
+            self.optimizer.content_discriminator = FusedAdam(
+                self.model.content_discriminator.parameters(), lr=args.lr / 2.5,
+                betas=(args.beta1, float(args.beta2)), weight_decay=args.wd)
+        self.gan_loss = losses.GANLoss(args.gan_mode)
+        self.classification_loss = losses.ClassificationLoss()
+        self.l1_loss = losses.L1Loss()
+        if getattr(args, "use_ragan", False):
+            raise NotImplementedError("--use_ragan is not implemented in this build (SURVEY.md 8f-4)")
+        if args.vgg_loss is not None:
+            raise NotImplementedError("--vgg_loss needs downloaded VGG weights; out of scope")
+        self.print_loss = ["g_adv", "g_cls", "l1_cc_rec"]
+
+    # ---- small helpers -------------------------------------------------------------------------
+    def get_z_random(self, bs, latent_dim):
+        return random_source().z((bs, latent_dim), self.device)
+
+    def set_inputs(self, inputs):
+        self.img_a = inputs["x1"].to(self.device, non_blocking=True).detach()
+        self.cls_a = inputs["y1"].to(self.device, non_blocking=True).detach().float()
+        self.img_b = inputs["x2"].to(self.device, non_blocking=True).detach()
+        self.cls_b = inputs["y2"].to(self.device, non_blocking=True).detach().float()
+        self.img = ops.canon(torch.cat((self.img_a, self.img_b), dim=0))     # one NCHW -> padded-NHWC pass
+        self.c_org = torch.cat((self.cls_a, self.cls_b), dim=0)
+
+    def _encode_style(self, img, c):
+        out = self.model.style_encoder(img, c)
+        return out if self.reparam else (out, None, None)
+
+    def _translate(self, contents, styles, classes):
+        B = self.args.batch_size
+        fake = self.model.decoder(ops.cat_batch(contents), torch.cat(styles, dim=0), torch.cat(classes, dim=0))
+        return torch.split(fake, B, dim=0)
+
+    def _reduce_and_step(self, names):
+        opts = [self.optimizer[n] for n in names]
+        handles = self.reducer.reduce([o.flat_grad() for o in opts])
+        for o, h in zip(opts, handles):
+            self.reducer.wait(h)
+            o.step()
+
+    # ---- inference surface (reference adain_model.py:96-134) --------------------------------------
+    def forward_random(self, img, z_r, c_trg):
+        start = time.time()
+        z_c = self.model.content_encoder(img)
+        img_fake = self.model.decoder(z_c, z_r, c_trg)
+        end = time.time()
+        return img_fake, end - start, torch.cuda.memory_reserved(0) / (1024 * 1024 * 1024)
+
+    def forward_reference(self, img_src, img_ref, c_trg):
+        start = time.time()
+        z_c = self.model.content_encoder(img_src)
+        z_s, _, _ = self._encode_style(img_ref, c_trg)
+        img_fake = self.model.decoder(z_c, z_s, c_trg)
+        end = time.time()
+        return img_fake, end - start, torch.cuda.memory_reserved(0) / (1024 * 1024 * 1024)
+
+    def forward(self, img, c_org):
+        B = self.args.batch_size
+        z_ca, z_cb = torch.split(self.model.content_encoder(img), B, dim=0)
+        z_s, _, _ = self._encode_style(img, c_org)
+        z_sa, z_sb = torch.split(z_s, B, dim=0)
+        z_sr = self.get_z_random(B, self.args.latent_dim)
+        cls_a, cls_b = torch.split(c_org, B, dim=0)
+        img_ba, img_aa, img_br = self._translate((z_cb, z_ca, z_cb), (z_sa, z_sa, z_sr), (cls_a, cls_a, cls_a))
+        img_ab, img_bb, img_ar = self._translate((z_ca, z_cb, z_ca), (z_sb, z_sb, z_sr), (cls_b, cls_b, cls_b))
+        return (ops.cat_batch((img_ba, img_ab)), ops.cat_batch((img_br, img_ar)), ops.cat_batch((img_aa, img_bb)))
+
+    # ---- content discriminator (optional; reference adain_model.py:136-144, 334-337) ---------------
+    def update_content_discriminator(self, img, c_org):
+        with torch.no_grad():
+            z_c = self.model.content_encoder(img)
+        self.optimizer.content_discriminator.zero_grad()
+        pred = self.model.content_discriminator(z_c.detach())
+        loss_d_content = self.classification_loss(pred, c_org)
+        loss_d_content.backward()
+        self.loss_dc = loss_d_content.detach()
+        opt = self.optimizer.content_discriminator
+        (h,) = self.reducer.reduce([opt.flat_grad()])
+        self.reducer.wait(h)
+        g = opt.flat_grad()
+        g.mul_(torch.clamp(5.0 / (g.norm() + 1e-6), max=1.0))      # clip_grad_norm_(…, 5)
+        opt.step()
+
+    def backward_content_discriminator(self, z_c):
+        pred = self.model.content_discriminator(z_c)
+        return self.classification_loss(pred, 1 - self.c_org)
+
+    # ---- PHASE 1-2 ----------------------------------------------------------------------------------
+    def update_discriminator(self, img, c_org):
+        B = self.args.batch_size
+        cls_a, cls_b = torch.split(c_org, B, dim=0)
+        with torch.no_grad():
+            z_ca, z_cb = torch.split(self.model.content_encoder(img), B, dim=0)
+            z_s, _, _ = self._encode_style(img, c_org)
+            z_sa, z_sb = torch.split(z_s, B, dim=0)
+            z_sr = self.get_z_random(B, self.args.latent_dim)
+            img_ba, img_br = self._translate((z_cb, z_cb), (z_sa, z_sr), (cls_a, cls_a))
+            img_ab, img_ar = self._translate((z_ca, z_ca), (z_sb, z_sr), (cls_b, cls_b))
+            img_fake = ops.cat_batch((img_ba, img_ab))
+            img_random = ops.cat_batch((img_br, img_ar))
+        for name, fake in (("discriminator1", img_fake), ("discriminator2", img_random)):
+            self.optimizer[name].zero_grad()
+            self.backward_discriminator(self.model[name], img, fake, c_org)
+            self._reduce_and_step((name,))
+
+    def _dis_outputs(self, netD, x):
+        out = netD(x)
+        return out if self.args.ms_dis else [out]
+
+    def backward_discriminator(self, netD, real, fake, c_org):
+        """covers the reference's backward_discriminator and backward_multi_scale_discriminator (182-223)"""
+        loss_d_adv, loss_d_cls = 0, 0
+        for (pf, _), (pr, cr) in zip(self._dis_outputs(netD, fake.detach()), self._dis_outputs(netD, real)):
+            loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
+            loss_d_cls = loss_d_cls + self.classification_loss(cr, c_org)
+        loss_d = loss_d_adv + self.args.lambda_cls * loss_d_cls
+        loss_d.backward()
+        self._set_loss(d_adv=loss_d_adv, d_cls=loss_d_cls, d_total=loss_d)
+
+    backward_multi_scale_discriminator = backward_discriminator
+
+    # ---- PHASE 3-4 ----------------------------------------------------------------------------------
+    def update_generator(self, img, c_org):
+        for n in ("content_encoder", "style_encoder", "decoder"):
+            self.optimizer[n].zero_grad()
+        self.backward_generator(img, c_org)
+        self._reduce_and_step(("content_encoder", "style_encoder", "decoder"))
+        for n in ("content_encoder", "decoder"):
+            self.optimizer[n].zero_grad()
+        self.backward_decoder_random(img, c_org)
+        self._reduce_and_step(("content_encoder", "decoder"))
+
+    def _generator_adv(self, netD, fake, c_org):
+        adv, cls = 0, 0
+        with ops.frozen(netD):
+            for pf, cf in self._dis_outputs(netD, fake):
+                adv = adv + self.gan_loss(pf, 1)
+                cls = cls + self.classification_loss(cf, c_org)
+        return adv, cls * self.args.lambda_cls_G
+
+    def backward_generator(self, img, c_org):
+        a, B = self.args, self.args.batch_size
+        cls_a, cls_b = torch.split(c_org, B, dim=0)
+        z_c = self.model.content_encoder(img)
+        z_ca, z_cb = torch.split(z_c, B, dim=0)
+        z_s, mu, logvar = self._encode_style(img, c_org)
+        z_sa, z_sb = torch.split(z_s, B, dim=0)
+        img_ba, img_aa = self._translate((z_cb, z_ca), (z_sa, z_sa), (cls_a, cls_a))
+        img_ab, img_bb = self._translate((z_ca, z_cb), (z_sb, z_sb), (cls_b, cls_b))
+        img_fake = ops.cat_batch((img_ba, img_ab))
+        img_self = ops.cat_batch((img_aa, img_bb))
+        # cross-cycle: re-encode the translations (note the swapped split order, adain_model.py:264-265)
+        z_c_rec_b, z_c_rec_a = torch.split(self.model.content_encoder(img_fake), B, dim=0)
+        z_s_rec, _, _ = self._encode_style(img_fake, c_org)
+        z_s_rec_a, z_s_rec_b = torch.split(z_s_rec, B, dim=0)
+        img_recon = self.model.decoder(ops.cat_batch((z_c_rec_a, z_c_rec_b)), torch.cat((z_s_rec_a, z_s_rec_b), dim=0),
+                                       torch.cat((cls_a, cls_b), dim=0))
+        loss_g_content = None
+        if a.use_dis_content:
+            with ops.frozen(self.model.content_discriminator):
+                loss_g_content = self.backward_content_discriminator(z_c)
+        loss_g_adv, loss_g_cls = self._generator_adv(self.model.discriminator1, img_fake, c_org)
+        loss_g_self = self.l1_loss(img, img_self) * a.lambda_rec
+        loss_g_cc = self.l1_loss(img, img_recon) * a.lambda_rec
+        loss_kl_zc = ops.l2_mean(z_c) * 0.01
+        if self.reparam:
+            loss_kl_zs = ops.kl_sum(mu, logvar) * 0.01
+            kl_for_grad = loss_kl_zs * float(self.reducer.world)       # batch SUM -> see module docstring
+        else:
+            loss_kl_zs = (z_s * z_s).mean() * 0.01
+            kl_for_grad = loss_kl_zs
+        loss_g = loss_g_adv + loss_g_cls + loss_g_self + loss_g_cc + loss_kl_zc
+        if loss_g_content is not None:
+            loss_g = loss_g + loss_g_content
+            self._set_loss(g_content=loss_g_content)
+        (loss_g + kl_for_grad).backward()
+        self._set_loss(g_adv=loss_g_adv, g_cls=loss_g_cls, kl_zc=loss_kl_zc, kl_zs=loss_kl_zs,
+                       l1_self_rec=loss_g_self, l1_cc_rec=loss_g_cc, total_g=(loss_g + loss_kl_zs))
+
+    def backward_decoder_random(self, img, c_org):
+        a, B = self.args, self.args.batch_size
+        cls_a, cls_b = torch.split(c_org, B, dim=0)
+        z_ca, z_cb = torch.split(self.model.content_encoder(img), B, dim=0)
+        z_sr = self.get_z_random(B, a.latent_dim)
+        img_br = self.model.decoder(z_cb, z_sr, cls_a)
+        img_ar = self.model.decoder(z_ca, z_sr, cls_b)
+        img_random = ops.cat_batch((img_br, img_ar))
+        # with --ms_dis the reference scores the random translations with discriminator1 (352-353)
+        netD = self.model.discriminator1 if a.ms_dis else self.model.discriminator2
+        loss_g_adv2, loss_g_cls2 = self._generator_adv(netD, img_random, c_org)
+        if self.reparam:
+            with ops.frozen(self.model.style_encoder):      # Es is not stepped in this phase (235-239)
+                _, mu2, _ = self._encode_style(img_random, c_org)
+            mu2_a, mu2_b = torch.split(mu2, B, dim=0)
+            loss_z_l1 = (self.l1_loss(mu2_a, z_sr) + self.l1_loss(mu2_b, z_sr)) * 10
+        else:
+            with ops.frozen(self.model.style_encoder):
+                z_rec, _, _ = self._encode_style(img_random, c_org)
+            z_rec_a, _ = torch.split(z_rec, B, dim=0)
+            loss_z_l1 = (self.l1_loss(z_rec_a, z_sr) + self.l1_loss(z_rec_a, z_sr)) * 10   # base_model.py:419-420
+        loss_g = loss_z_l1 + loss_g_adv2 + loss_g_cls2
+        loss_g.backward()
+        self._set_loss(l1_recon_z=loss_z_l1, gan2=loss_g_adv2, gan2_cls=loss_g_cls2)
+
+    # ---- visuals / dispatch ---------------------------------------------------------------------------
+    def compute_visuals(self):
+        B = self.args.batch_size
+        with torch.no_grad():
+            img_fake, img_random, img_self = self.forward(self.img, self.c_org)
+        fa, fb = torch.split(img_fake, B, dim=0)
+        ra, rb = torch.split(img_random, B, dim=0)
+        sa, sb = torch.split(img_self, B, dim=0)
+        f32 = ops.to_nchw_f32
+        ia, ib = torch.split(f32(self.img), B, dim=0)
+        row1 = torch.cat((ia[0:1], f32(fb)[0:1], f32(rb)[0:1], f32(sa)[0:1]), dim=3)
+        row2 = torch.cat((ib[0:1], f32(fa)[0:1], f32(ra)[0:1], f32(sb)[0:1]), dim=3)
+        return torch.cat((row1, row2), dim=2)
+
+    def normalize_image(self, x):
+        return x[:, 0:3, :, :]
+
+    def optimize_parameters(self, global_iter):
+        if self.args.use_dis_content and global_iter % self.args.d_iter != 0:
+            self.update_content_discriminator(self.img, self.c_org)
+            return
+        self.update_discriminator(self.img, self.c_org)
+        self.update_generator(self.img, self.c_org)

@@ -1,0 +1,97 @@
+"""FusedAdam: ``torch.optim.Adam`` semantics (L2-coupled weight decay, bias correction; reference
+adain_model.py:57-61,68-71) executed as ONE HIP launch per optimizer over flat fp32 buffers.
+
+Parameters, gradients and both moments of a network are views into four flat device buffers, so
+ * ``step()`` is a single ``mt_adam_multi`` launch (no per-tensor kernels, no pointer chasing),
+ * ``zero_grad()`` is one memset,
+ * the data-parallel gradient exchange is one RCCL all-reduce of ``flat_grad`` per backward phase.
+``state_dict()`` / ``load_state_dict()`` keep torch.optim.Adam's format so ``opt_{it}.ckpt`` files
+interchange with the reference (model.py:70-100).
+"""
+import torch
+
+from . import hip_ops as ops
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=weight_decay)
+        self._flat = None
+        self._step_count_mt = 0
+
+    # ---- flat storage ----
+    def params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def _flatten(self):
+        ps = self.params()
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdam steps on the HIP device only (no CPU fallback)")
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) & ~3          # keep every view 16-byte aligned
+        fp = torch.zeros(total, dtype=torch.float32, device=dev)
+        fg = torch.zeros(total, dtype=torch.float32, device=dev)
+        fm = torch.zeros(total, dtype=torch.float32, device=dev)
+        fv = torch.zeros(total, dtype=torch.float32, device=dev)
+        step = 0
+        for p, o in zip(ps, offs):
+            n = p.numel()
+            fp[o:o + n].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                fg[o:o + n].copy_(p.grad.reshape(-1))
+            st = self.state.get(p, {})
+            if "exp_avg" in st:
+                fm[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                fv[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = max(step, int(torch.as_tensor(st["step"]).item()))
+            p.data = fp[o:o + n].view(p.shape)
+            p.grad = fg[o:o + n].view(p.shape)
+            self.state[p] = {"step": torch.tensor(float(step)), "exp_avg": fm[o:o + n].view(p.shape),
+                             "exp_avg_sq": fv[o:o + n].view(p.shape)}
+        self._step_count_mt = step
+        self._flat = (fp, fg, fm, fv, total)
+        self._ptrs = torch.tensor([fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr()], dtype=torch.int64).to(dev)
+        self._sizes = torch.tensor([total], dtype=torch.int64).to(dev)
+        ops.bump_epoch(ps)
+
+    def flat_grad(self):
+        if self._flat is None:
+            self._flatten()
+        return self._flat[1]
+
+    def flat_param(self):
+        if self._flat is None:
+            self._flatten()
+        return self._flat[0]
+
+    # ---- torch.optim API ----
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad().zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._flat is None:
+            self._flatten()
+        g = self.param_groups[0]
+        self._step_count_mt += 1
+        import ctypes as C
+        from . import _lib as L
+        b1, b2 = g["betas"]
+        L.check(L.load().mt_adam_multi(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
+                                       self._flat[4], float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                       float(g["weight_decay"]), self._step_count_mt,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mt_adam_multi")
+        ops.bump_epoch(self.params())
+
+    def state_dict(self):
+        for p in self.params():
+            if p in self.state and "step" in self.state[p]:
+                self.state[p]["step"] = torch.tensor(float(self._step_count_mt))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = None   # re-flatten (copies the loaded moments) at the next use
