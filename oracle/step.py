@@ -32,8 +32,8 @@ class TorchRng:
 class ReplayRng:
     """Replays the list of tensors recorded from a reference run (tests/golden)."""
 
-    def __init__(self, tensors):
-        self.t = [torch.as_tensor(x) for x in tensors]
+    def __init__(self, tensors, dtype=torch.float32):
+        self.t = [torch.as_tensor(x).to(dtype) for x in tensors]
         self.i = 0
 
     def _next(self, shape):
@@ -85,10 +85,12 @@ def gan_loss(mode, x, real):
 class OracleModel:
     """Functional twin of the reference ``Model``: ``P[net][key]`` leaf tensors + one Adam each."""
 
-    def __init__(self, params, args):
+    def __init__(self, params, args, dtype=torch.float32):
+        """dtype=torch.float64 gives a high-precision ground truth for gradient comparisons."""
         self.args = args
+        self.dtype = dtype
         self.kind = "adain" if args.model == "AdaINModel" else "base"
-        self.P = {net: {k: torch.as_tensor(v).clone().float().requires_grad_(True) for k, v in sd.items()}
+        self.P = {net: {k: torch.as_tensor(v).clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
                   for net, sd in params.items()}
         self.opt, self.sched = {}, {}
         for net, sd in self.P.items():
@@ -130,8 +132,8 @@ class OracleModel:
             s.step()
 
     def set_inputs(self, batch):                            # adain_model.py:87-94
-        self.img = torch.cat((batch["x1"], batch["x2"]), dim=0).float()
-        self.c_org = torch.cat((batch["y1"], batch["y2"]), dim=0).float()
+        self.img = torch.cat((batch["x1"], batch["x2"]), dim=0).to(self.dtype)
+        self.c_org = torch.cat((batch["y1"], batch["y2"]), dim=0).to(self.dtype)
 
     def _d_phase(self, which, real, fake, c_org):           # adain_model.py:182-223
         a = self.args
