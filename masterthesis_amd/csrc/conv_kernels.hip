@@ -541,39 +541,50 @@ int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, 
 // bias gradient: db[c] = sum over pixels of dy[pixel][c]   (fp32 atomics into zeroed db)
 // ------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ db, long npix, int cchunks,
-                              int C, int pix_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ db, long npix,
+                                                     int cchunks, int C, int pix_per_block) {
   constexpr int V = Elem<BF16>::V;
+  __shared__ float red[256];
   const int cq = threadIdx.x % cchunks;
   const int pl = threadIdx.x / cchunks;
   const int npl = blockDim.x / cchunks;
-  if (pl >= npl) return;
   const long p0 = (long)blockIdx.x * pix_per_block;
   const long p1 = min(npix, p0 + pix_per_block);
   float accv[V];
 #pragma unroll
   for (int e = 0; e < V; e++) accv[e] = 0.f;
-  for (long px = p0 + pl; px < p1; px += npl) {
-    float f[V];
-    Elem<BF16>::unpack(dy[px * cchunks + cq], f);
+  if (pl < npl) {
+    for (long px = p0 + pl; px < p1; px += npl) {
+      float f[V];
+      Elem<BF16>::unpack(dy[px * cchunks + cq], f);
 #pragma unroll
-    for (int e = 0; e < V; e++) accv[e] += f[e];
+      for (int e = 0; e < V; e++) accv[e] += f[e];
+    }
   }
+  // tree over the pixel lanes in LDS, then ONE atomic per (block, channel)
 #pragma unroll
   for (int e = 0; e < V; e++) {
-    const int ch = cq * V + e;
-    if (ch < C) atomicAdd(db + ch, accv[e]);
+    __syncthreads();
+    red[threadIdx.x] = accv[e];
+    __syncthreads();
+    if (pl == 0) {
+      float a = 0.f;
+      for (int k = 0; k < npl; k++) a += red[k * cchunks + cq];
+      const int ch = cq * V + e;
+      if (ch < C) atomicAdd(db + ch, a);
+    }
   }
 }
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
-  MT_CHECK(cchunks <= 1024, "colsum: too many channels %d", Cp);
+  MT_CHECK(cchunks <= 256, "colsum: too many channels %d", Cp);
   if (hipMemsetAsync(db, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("colsum memset failed"); return 2; }
   if (npix == 0) return 0;
-  int threads = 256;
-  while (threads < cchunks) threads *= 2;
-  const int ppb = 2048;
+  const int threads = 256;
+  const int npl = threads / cchunks;
+  int ppb = npl * 64;  // 64 pixels per thread
+  if (ppb < 256) ppb = 256;
   const int blocks = (int)((npix + ppb - 1) / ppb);
   if (dtype == MT_BF16)
     hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, db, npix, cchunks, C, ppb);

@@ -42,14 +42,21 @@ extern "C" int mt_linear_fwd(const float* x, const float* w, const float* b, flo
   return 0;
 }
 // dx[n][i] = sum_o dy[n][o] w[o][i];  dw[o][i] = sum_n dy[n][o] x[n][i];  db[o] = sum_n dy[n][o]
-__global__ void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                     float* __restrict__ dx, int n, int in, int out) {
-  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (idx >= (long)n * in) return;
-  const int r = (int)(idx / in), i = (int)(idx % in);
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int n, int in, int out) {
+  // block = 64 consecutive input features of one row x 4 slices of the output dimension
+  __shared__ float red[256];
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
   float a = 0.f;
-  for (int o = 0; o < out; o++) a += dy[(long)r * out + o] * w[(long)o * in + i];
-  dx[idx] = a;
+  if (i < in) {
+#pragma unroll 8
+    for (int o = sl; o < out; o += 4) a += dy[(long)r * out + o] * w[(long)o * in + i];
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (sl == 0 && i < in) dx[(long)r * in + i] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                      float* __restrict__ dw, float* __restrict__ db, int n, int in, int out) {
@@ -69,7 +76,7 @@ extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, fl
                              int n, int in, int out, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   if (n == 0) return 0;
-  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)n * in, 256)), dim3(256), 0, s, w, dy, dx, n, in, out);
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(in, 64), n), dim3(256), 0, s, w, dy, dx, n, in, out);
   if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)out * in, 256)), dim3(256), 0, s, x, dy, dw, db, n, in, out);
   MT_LAUNCH_CHECK();
   return 0;

@@ -166,19 +166,29 @@ extern "C" int mt_norm_finalize(int mode, const float* sums, const float* gb, co
   return 0;
 }
 
-// y = act(scale*x + shift) (+res); elementwise over 16-byte chunks. grid-stride.
+// y = act(scale*x + shift) (+res).  grid = (pixel blocks, N); a thread keeps ONE channel chunk for its
+// whole pixel loop, so the per-(n,c) coefficients sit in registers and the inner loop is load-fma-store.
 template <bool BF16>
-__global__ void scale_shift_act_kernel(const u32x4* __restrict__ x, const float* __restrict__ scale,
-                                       const float* __restrict__ shift, const u32x4* __restrict__ res,
-                                       u32x4* __restrict__ y, long total, int HW, int cchunks, int act,
-                                       float slope) {
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const u32x4* __restrict__ x,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const u32x4* __restrict__ res, u32x4* __restrict__ y,
+                                                              int HW, int cchunks, int pix_per_block, int act,
+                                                              float slope) {
   constexpr int V = Elem<BF16>::V;
-  const long per_img = (long)HW * cchunks;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / per_img);
-    const int cq = (int)(i % cchunks);
-    const float* sc = scale + ((long)n * cchunks + cq) * V;
-    const float* sh = shift + ((long)n * cchunks + cq) * V;
+  const int n = blockIdx.y;
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float sc[V], sh[V];
+  const long co = ((long)n * cchunks + cq) * V;
+#pragma unroll
+  for (int e = 0; e < V; e++) { sc[e] = scale[co + e]; sh[e] = shift[co + e]; }
+  const long base = (long)n * HW * cchunks + cq;
+  for (int px = p0 + pl; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
     float f[V], r[V];
     Elem<BF16>::unpack(x[i], f);
     if (res) Elem<BF16>::unpack(res[i], r);
@@ -191,18 +201,28 @@ __global__ void scale_shift_act_kernel(const u32x4* __restrict__ x, const float*
     y[i] = Elem<BF16>::pack(f);
   }
 }
+static inline void ew_geometry(int HW, int cchunks, int N, int* threads, int* ppb, dim3* grid) {
+  *threads = (256 / cchunks) * cchunks;       // every thread owns one channel chunk
+  const int npl = *threads / cchunks;
+  int p = npl * 8;                            // 8 chunks per thread
+  if (p < 1) p = 1;
+  *ppb = p;
+  *grid = dim3(cdiv(HW, p), N);
+}
 extern "C" int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
                                   const void* res, void* y, int N, int HW, int Cp, int act, float slope,
                                   mt_stream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
-  const long total = (long)N * HW * cchunks;
-  if (total == 0) return 0;
-  const int blocks = (int)min((long)16384, (total + 255) / 256);
+  MT_CHECK(cchunks >= 1 && cchunks <= 256, "scale_shift_act: unsupported channel count %d", Cp);
+  if ((long)N * HW == 0) return 0;
+  int threads, ppb;
+  dim3 grid;
+  ew_geometry(HW, cchunks, N, &threads, &ppb, &grid);
   if (dtype == MT_BF16)
-    hipLaunchKernelGGL((scale_shift_act_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, total, HW, cchunks, act, slope);
+    hipLaunchKernelGGL((scale_shift_act_kernel<true>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, HW, cchunks, ppb, act, slope);
   else
-    hipLaunchKernelGGL((scale_shift_act_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, total, HW, cchunks, act, slope);
+    hipLaunchKernelGGL((scale_shift_act_kernel<false>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)x, scale, shift, (const u32x4*)res, (u32x4*)y, HW, cchunks, ppb, act, slope);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -290,24 +310,36 @@ extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* m
 }
 
 template <bool BF16>
-__global__ void norm_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
-                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                      const float* __restrict__ c1, const float* __restrict__ c2,
-                                      const float* __restrict__ c3, u32x4* __restrict__ dx, long total, int HW,
-                                      int cchunks, int act, float slope) {
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ c1, const float* __restrict__ c2,
+                                                             const float* __restrict__ c3, u32x4* __restrict__ dx, int HW,
+                                                             int cchunks, int pix_per_block, int act, float slope) {
   constexpr int V = Elem<BF16>::V;
-  const long per_img = (long)HW * cchunks;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / per_img);
-    const int cq = (int)(i % cchunks);
-    const long o = ((long)n * cchunks + cq) * V;
+  const int n = blockIdx.y;
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float sc[V], sh[V], k1[V], k2[V], k3[V];
+  const long co = ((long)n * cchunks + cq) * V;
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    sc[e] = scale[co + e]; sh[e] = shift[co + e];
+    k1[e] = c1[co + e]; k2[e] = c2[co + e]; k3[e] = c3[co + e];
+  }
+  const long base = (long)n * HW * cchunks + cq;
+  for (int px = p0 + pl; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
     float f[V], g[V];
     Elem<BF16>::unpack(x[i], f);
     Elem<BF16>::unpack(dy[i], g);
 #pragma unroll
     for (int e = 0; e < V; e++) {
-      const float gg = g[e] * act_grad_z(scale[o + e] * f[e] + shift[o + e], act, slope);
-      f[e] = c1[o + e] * gg + c2[o + e] + c3[o + e] * f[e];
+      const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
+      f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
     }
     dx[i] = Elem<BF16>::pack(f);
   }
@@ -317,13 +349,15 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
                                  int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
-  const long total = (long)N * HW * cchunks;
-  if (total == 0) return 0;
-  const int blocks = (int)min((long)16384, (total + 255) / 256);
+  MT_CHECK(cchunks >= 1 && cchunks <= 256, "norm_bwd_apply: unsupported channel count %d", Cp);
+  if ((long)N * HW == 0) return 0;
+  int threads, ppb;
+  dim3 grid;
+  ew_geometry(HW, cchunks, N, &threads, &ppb, &grid);
   if (dtype == MT_BF16)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, total, HW, cchunks, act, slope);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
   else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, total, HW, cchunks, act, slope);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -117,7 +117,6 @@ def _act_code(act):
 # packed-weight cache.  Parameters keep the reference layout (checkpoint compatible); the
 # MFMA tile images are rebuilt only when a parameter changed (optimizer step / load).
 # --------------------------------------------------------------------------------------
-_PACKS = {}
 _EPOCH = {}
 
 
@@ -128,22 +127,49 @@ def bump_epoch(params):
         _EPOCH[k] = _EPOCH.get(k, 0) + 1
 
 
-def clear_pack_cache():
-    _PACKS.clear()
-
-
-def _get_pack(weight, desc, which):
-    key = (weight.data_ptr(), which, desc.dtype, desc.transposed, desc.stride, desc.kh, desc.kw)
-    tag = (weight._version, _EPOCH.get(weight.data_ptr(), 0), tuple(weight.shape))
-    hit = _PACKS.get(key)
+def _get_pack(owner, weight, desc, which):
+    """``owner`` is the nn.Parameter object: the cache lives ON it, so it dies with the parameter and can
+    never be confused with another tensor that later reuses the same device address."""
+    cache = getattr(owner, "_mt_packs", None)
+    if cache is None:
+        cache = {}
+        try:
+            owner._mt_packs = cache
+        except AttributeError:
+            pass
+    key = (which, desc.dtype, desc.transposed, desc.stride, desc.kh, desc.kw)
+    tag = (owner._version, weight.data_ptr(), _EPOCH.get(weight.data_ptr(), 0), tuple(weight.shape))
+    hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     lib = L.load()
     nbytes = lib.mt_conv_pack_bytes(C.byref(desc), which)
     pack = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=weight.device)
     L.check(lib.mt_conv_pack(C.byref(desc), which, _ptr(weight), _ptr(pack), _stream()), "mt_conv_pack")
-    _PACKS[key] = (tag, pack)
+    cache[key] = (tag, pack)
     return pack
+
+
+# --------------------------------------------------------------------------------------
+# optional HIP-event timing of selected forward-conv launches (used by bench.py's roofline leg)
+# --------------------------------------------------------------------------------------
+_KTIMER = {"match": None, "events": []}
+
+
+def kernel_timer_start(match):
+    """Time every conv forward whose descriptor satisfies ``match(desc)`` with HIP events recorded on the
+    launch stream."""
+    _KTIMER["match"] = match
+    _KTIMER["events"] = []
+
+
+def kernel_timer_stop():
+    """-> list of (milliseconds, batch N of the launch) per timed launch (synchronises)."""
+    _KTIMER["match"] = None
+    torch.cuda.synchronize()
+    out = [(a.elapsed_time(b), n) for a, b, n in _KTIMER["events"]]
+    _KTIMER["events"] = []
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -156,6 +182,7 @@ class _Conv(torch.autograd.Function):
         lib = L.load()
         dt = compute_dtype()
         x = canon(x)
+        owner = weight
         weight = _f32c(weight.detach())
         N, Ci, H, W = x.shape
         if transposed:
@@ -169,10 +196,19 @@ class _Conv(torch.autograd.Function):
         ho, wo = C.c_int(), C.c_int()
         L.check(lib.mt_conv_out_hw(C.byref(desc), C.byref(ho), C.byref(wo)), "mt_conv_out_hw")
         y = new_act(N, Co, ho.value, wo.value, dt, x.device)
-        pack = _get_pack(weight, desc, L.PACK_FWD)
+        pack = _get_pack(owner, weight, desc, L.PACK_FWD)
         b = None if bias is None else _f32c(bias.detach())
+        timed = _KTIMER["match"] is not None and _KTIMER["match"](desc)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()), "mt_conv_fwd")
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _KTIMER["events"].append((e0, e1, N))
         ctx.desc = desc
+        ctx.owner = owner
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         return y
@@ -191,7 +227,7 @@ class _Conv(torch.autograd.Function):
             dy = dz
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            pack = _get_pack(weight, desc, L.PACK_BWD_DATA)
+            pack = _get_pack(ctx.owner, weight, desc, L.PACK_BWD_DATA)
             nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dy.device)
             dx = new_act(*x.shape, dy.dtype, dy.device)
