@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int NWP = PT / WP;                  // waves along the pixel dimension
   constexpr int FC = WC / 16, FP = WP / 16;
   constexpr int SZ = BF16 ? 2 : 4;
-  constexpr int WLD = (WT * 8 + 255) / 256;     // weight chunks staged per thread per k-step
+  constexpr int WLD = (WT * 8 + 255) / 256;     // weight-tile LDS-DMA instructions per wave per k-step
 
   __shared__ u32x4 sW[2][WT * 8];
   __shared__ u32x4 sX[2][PT * 8];
@@ -63,47 +63,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int wt = wg % nWT, pt = wg / nWT;
 
   // ---- per-thread staging coordinates (fixed over the k loop) ----
-  const int c = tid & 7, r0 = tid >> 3;
+  // All global offsets are 32-bit byte offsets from the tensor base (host checks < 4 GiB), advanced
+  // incrementally: inside one filter tap a k-step is just "+128 bytes"; the reflect / bounds math runs
+  // only when the tap changes.  Keeps the VALU stream short next to the MFMAs.
+  // Staging is LDS-DMA (buffer_load ... lds): a wave instruction writes 64 x 16 B = 8 tile rows
+  // lane-linearly, so the XOR bank swizzle is applied on the SOURCE side: lane (row r, slot pc) fetches
+  // logical chunk pc ^ (r & 7) and the fragment reads apply the same XOR.
+  const int r0 = tid >> 3;
+  const int c = (tid & 7) ^ (r0 & 7);
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HoWo = p.Ho * p.Wo;
   int hb[4], wb[4];
-  size_t ib[4];
-  bool rv[4];
+  unsigned ib[4];
+  unsigned rvm = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int m = pt * PT + r0 + 32 * i;
-    rv[i] = m < p.M;
-    const int mm = rv[i] ? m : 0;
+    const bool rv = m < p.M;
+    rvm |= (rv ? 1u : 0u) << i;
+    const int mm = rv ? m : 0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
     const int ho = rem / p.Wo;
     const int wo = rem - ho * p.Wo;
     hb[i] = ho * p.is;
     wb[i] = wo * p.is;
-    ib[i] = (size_t)n * p.Hi * p.Wi * p.Cib;
+    ib[i] = (unsigned)n * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
   }
   int q = c;
   int tap = q / p.cpc;
   int cq = q - tap * p.cpc;
   const int step_t = 8 / p.cpc, step_r = 8 % p.cpc;
 
-  u32x4 xr[4], wr[WLD];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  auto gload = [&]() {
+  unsigned wo32[WLD];
+  unsigned wokm = 0;
 #pragma unroll
-    for (int i = 0; i < WLD; i++) {
-      const int rl = r0 + 32 * i;
-      const int row = wt * WT + rl;
-      const bool ok = (rl < WT) && (row < p.CoRows) && (q < p.nchunks);
-      wr[i] = ok ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)row * p.nchunks + q) * 16) : zero4;
-    }
+  for (int i = 0; i < WLD; i++) {
+    const int rl = r0 + 32 * i;
+    const int row = wt * WT + rl;
+    const bool ok = (rl < WT) && (row < p.CoRows);
+    wokm |= (ok ? 1u : 0u) << i;
+    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)p.nchunks + (unsigned)c) * 16u;
+  }
+  unsigned xo32[4];
+  unsigned xokm = 0;
+  auto retap = [&]() {
+    xokm = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) xo32[i] = 0xfffffff0u;
     if (tap < p.ntaps) {
       const int t = sTap[tap];
       const int dh = t >> 16, dw = (int)(short)(t & 0xffff);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         int hi = hb[i] + dh, wi = wb[i] + dw;
-        bool ok = rv[i];
+        bool ok = (rvm >> i) & 1u;
         if (p.pad_mode == MT_PAD_REFLECT) {
           hi = hi < 0 ? -hi : hi;
           hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
@@ -111,29 +125,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
         } else {
           ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+          hi = ok ? hi : 0;
+          wi = ok ? wi : 0;
         }
-        const size_t off = ib[i] + ((size_t)hi * p.Wi + wi) * p.Cib + (size_t)cq * 16;
-        xr[i] = ok ? *reinterpret_cast<const u32x4*>(p.x + off) : zero4;
+        // invalid lanes get an out-of-range offset: the buffer load returns zeros for them
+        xo32[i] = ok ? ib[i] + (unsigned)(hi * p.Wi + wi) * (unsigned)p.Cib + (unsigned)cq * 16u : 0xfffffff0u;
+        xokm |= (ok ? 1u : 0u) << i;
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) xr[i] = zero4;
     }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // issue the asynchronous global->LDS copies of the next k-step into buffer `buf`
+  auto issue = [&](int buf) {
+    const bool kin = q < p.nchunks;
+    char* lw = reinterpret_cast<char*>(&sW[buf][0]);
+    char* lx = reinterpret_cast<char*>(&sX[buf][0]);
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      if (wvu * 8 + 32 * i < WT) {
+        const unsigned o = (kin && ((wokm >> i) & 1u)) ? wo32[i] : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(lw + (wvu * 8 + 32 * i) * 128), 16, o, 0, 0, 0);
+      }
+      wo32[i] += 128u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(lx + (wvu * 8 + 32 * i) * 128), 16, xo32[i], 0, 0, 0);
+    // advance to the next k-step
     q += 8;
+    const int otap = tap;
     tap += step_t;
     cq += step_r;
     if (cq >= p.cpc) { cq -= p.cpc; tap++; }
-  };
-  auto lstore = [&](int buf) {
+    if (tap != otap) {
+      retap();
+    } else {
 #pragma unroll
-    for (int i = 0; i < WLD; i++) {
-      const int rl = r0 + 32 * i;
-      if (rl < WT) sW[buf][rl * 8 + (c ^ (rl & 7))] = wr[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int rl = r0 + 32 * i;
-      sX[buf][rl * 8 + (c ^ (rl & 7))] = xr[i];
+      for (int i = 0; i < 4; i++) xo32[i] += ((xokm >> i) & 1u) ? 128u : 0u;
     }
   };
 
@@ -145,13 +176,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   const int nk = (p.nchunks + 7) >> 3;
   __syncthreads();  // sTap visible
-  if (nk > 0) { gload(); lstore(0); }
-  __syncthreads();
+  retap();
+  if (nk > 0) issue(0);
 
   for (int ks = 0; ks < nk; ks++) {
     const int cur = ks & 1;
-    const bool more = (ks + 1) < nk;
-    if (more) gload();  // global loads for the next k-step fly under this step's MFMAs
+    // drains this wave's LDS-DMA (vmcnt(0)) and joins the block: buffer `cur` is complete, and every wave
+    // has finished reading buffer `cur^1` (k-step ks-1), so it may be overwritten now
+    __syncthreads();
+    if (ks + 1 < nk) issue(cur ^ 1);  // flies under this step's MFMAs
 #pragma unroll
     for (int kc = 0; kc < 2; kc++) {
       u32x4 wf[FC], xf[FP];
@@ -170,8 +203,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue: bias + activation, packed NHWC store (4 consecutive channels per lane) ----
@@ -227,6 +258,14 @@ static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(p.ntaps <= 64, "igemm: %d taps > 64", p.ntaps);
+  MT_CHECK((double)p.N * p.Hi * p.Wi * p.Cib < 4294967000.0, "igemm: input tensor exceeds 4 GiB (32-bit offsets)");
+  MT_CHECK((double)p.CoRows * p.nchunks * 16.0 < 4294967000.0, "igemm: weight pack exceeds 4 GiB");
+  IgemmParams q = p;
+  q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
+  q.w_bytes = (unsigned)((size_t)p.CoRows * p.nchunks * 16);
+  return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
+}
+static int unused_igemm_tail(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
   return dtype == MT_BF16 ? launch_igemm_t<true>(p, s) : launch_igemm_t<false>(p, s);
 }

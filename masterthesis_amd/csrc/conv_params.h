@@ -13,6 +13,8 @@ struct IgemmParams {
   char* y;            // output NHWC [N][Hout][Wout][Co]
   int N, Hi, Wi;
   int Cib;            // bytes per input pixel (padded channels * element size)
+  unsigned x_bytes;   // size of the input tensor / weight pack in bytes (hardware range check of the
+  unsigned w_bytes;   // buffer loads: out-of-range lanes read zeros -> zero padding costs no branch)
   int Ho, Wo, M;      // GEMM pixel grid, M = N*Ho*Wo
   int Co;             // padded output channels (elements per output pixel)
   int CoRows;         // rows of the weight pack (== Co)
@@ -36,6 +38,7 @@ struct WgradParams {
   float* out;      // fp32 [CaRows][nchunks * V]; accumulated with atomics (caller zeroes)
   int N, Hi, Wi;
   int Cab, Cbb;    // bytes per pixel
+  unsigned a_bytes, b_bytes;  // tensor sizes in bytes (buffer-load range checks)
   int CaRows;      // padded channel count of a
   int Ho, Wo, M;   // pixel grid of a
   int is;
