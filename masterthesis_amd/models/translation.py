@@ -165,9 +165,14 @@ class TranslationModel(Model):
         return out if self.args.ms_dis else [out]
 
     def backward_discriminator(self, netD, real, fake, c_org):
-        """covers the reference's backward_discriminator and backward_multi_scale_discriminator (182-223)"""
+        """covers the reference's backward_discriminator and backward_multi_scale_discriminator (182-223).
+        The fake and the real batch go through the discriminator as ONE concatenated batch (same weights,
+        per-sample independent layers => identical outputs, half the launches, twice the pixels per GEMM)."""
+        n = fake.shape[0]
         loss_d_adv, loss_d_cls = 0, 0
-        for (pf, _), (pr, cr) in zip(self._dis_outputs(netD, fake.detach()), self._dis_outputs(netD, real)):
+        for pred, cls in self._dis_outputs(netD, ops.cat_batch((fake.detach(), real))):
+            pf, pr = torch.split(pred, n, dim=0)
+            cr = cls[n:]
             loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
             loss_d_cls = loss_d_cls + self.classification_loss(cr, c_org)
         loss_d = loss_d_adv + self.args.lambda_cls * loss_d_cls
