@@ -194,8 +194,31 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
 }
 
+// pixel-split of the weight-gradient reduction: enough (tile, split) blocks to fill 256 CUs x 2
+static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk) {
+  const int V = vec(d->dtype);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  const int rows = d->transposed ? Cip : Cop, cols = (d->transposed ? Cop : Cip) * K2;
+  (void)V;
+  const int tiles = cdiv(rows, 128) * cdiv(cols, 128);
+  // 256 CUs x 2 resident blocks = 512 slots: fill exactly one round (a 1.3-round grid costs two rounds)
+  int ns = 512 / tiles;
+  const int maxsplit = cdiv(M, 256);
+  if (ns > maxsplit) ns = maxsplit;
+  if (ns < 1) ns = 1;
+  *mchunk = cdiv(cdiv(M, ns), 64) * 64;
+  *nsplit = cdiv(M, *mchunk);
+}
+static int wgrad_pixels(const mt_conv_desc* d) {
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  return d->transposed ? d->N * d->H * d->W : d->N * Ho * Wo;
+}
+
 extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
-  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+  int ns, mc;
+  wgrad_split(d, wgrad_pixels(d), &ns, &mc);
+  return (size_t)ns * mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
 }
 
 extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
@@ -236,19 +259,10 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   p.M = d->N * p.Ho * p.Wo;
   p.nchunks = p.ntaps * p.cpc;
   const int ncols = p.nchunks * V;
-  const int tiles = cdiv(p.CaRows, 128) * cdiv(ncols, 128);
-  int nsplit = cdiv(768, tiles);
-  const int maxsplit = cdiv(p.M, 256);
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit < 1) nsplit = 1;
-  p.mchunk = cdiv(cdiv(p.M, nsplit), 64) * 64;
-  nsplit = cdiv(p.M, p.mchunk);
-  if (hipMemsetAsync(ws, 0, (size_t)p.CaRows * ncols * sizeof(float), s) != hipSuccess) {
-    mt_set_error("conv_bwd_weight: memset failed");
-    return 2;
-  }
+  int nsplit;
+  wgrad_split(d, p.M, &nsplit, &p.mchunk);
   if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
-  if (mt_launch_unpack((const float*)ws, dw, u, s)) return 2;
+  if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, s)) return 2;
   if (dbias != nullptr) {
     if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, s)) return 2;
   }

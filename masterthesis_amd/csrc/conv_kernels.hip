@@ -295,11 +295,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int nAT = (p.CaRows + 127) / 128;
   const int at = blockIdx.x % nAT, bt = blockIdx.x / nAT;
   const int mbeg = blockIdx.y * p.mchunk;
-  const int mend = min(p.M, mbeg + p.mchunk);
-  if (mbeg >= mend) return;
+  const int mend = min(p.M, mbeg + p.mchunk);   // host guarantees mbeg < mend for every split
 
-  // staging coordinates
-  const int cc = tid % CPR, rr = tid / CPR;
+  // staging coordinates.  LDS-DMA writes a wave's 64 x 16 B lane-linearly (4 bf16 / 2 fp32 tile rows per
+  // instruction), so the bank swizzle is applied to the SOURCE chunk each lane fetches:
+  //   bf16: 32-byte slots XOR key(row), key = row bits {0,1,3}  (conflict-free ds_read_b64_tr_b16)
+  //   fp32: 64-byte slots XOR (row & 7)
+  const int pc = tid % CPR, rr = tid / CPR;
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int cc;
+  if constexpr (BF16) cc = pc ^ ((((rr & 3) | ((rr >> 1) & 4))) << 1);
+  else cc = pc ^ ((rr & 7) << 2);
   // A: channel chunk
   const int a_ch0 = at * 128 + cc * V;
   const bool a_ok = a_ch0 < p.CaRows;
@@ -313,32 +319,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     bdh = p.dh[btap];
     bdw = p.dw[btap];
   }
-  // pixel coordinates of the NLD rows this thread stages, advanced by KP every step
-  int pn[NLD], pho[NLD], pwo[NLD];
-  const int HoWo = p.Ho * p.Wo;
+  // pixel coordinates of the NLD rows this thread stages, advanced by KP every step.  Everything is kept
+  // incrementally (no integer multiplies by runtime strides in the loop except the final byte scaling):
+  //   nb = n*Hi*Wi, hraw = ho*is + dh, wraw = wo*is + dw
+  int nb[NLD], pho[NLD], pwo[NLD], hraw[NLD], wraw[NLD];
+  const int HoWo = p.Ho * p.Wo, HiWi = p.Hi * p.Wi;
 #pragma unroll
   for (int i = 0; i < NLD; i++) {
     const int m = mbeg + rr + RPT * i;
-    pn[i] = m / HoWo;
-    const int rem = m - pn[i] * HoWo;
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
     pho[i] = rem / p.Wo;
     pwo[i] = rem - pho[i] * p.Wo;
+    nb[i] = n * HiWi;
+    hraw[i] = pho[i] * p.is + bdh;
+    wraw[i] = pwo[i] * p.is + bdw;
   }
   const int adv_h = KP / p.Wo, adv_w = KP % p.Wo;
-
-  u32x4 ar[NLD], br[NLD];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int adv_h_is = adv_h * p.is, adv_w_is = adv_w * p.is, Wo_is = p.Wo * p.is, Ho_is = p.Ho * p.is;
+  const bool simple_adv = HoWo >= KP;   // at most one row wrap and one image wrap per step
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
   int mrow = mbeg + rr;  // pixel index of row i=0 for the next load
+  unsigned ao32 = (unsigned)mrow * (unsigned)p.Cab + (unsigned)a_ch0 * (unsigned)(16 / V);
+  const unsigned a_step = (unsigned)RPT * (unsigned)p.Cab;
+  const unsigned bcq16 = (unsigned)bcq * 16u;
 
-  auto gload = [&]() {
+  // asynchronous global->LDS copies of the next KP pixels into buffer `buf`
+  auto issue = [&](int buf) {
+    char* la = reinterpret_cast<char*>(&sA[buf][0]);
+    char* lb = reinterpret_cast<char*>(&sB[buf][0]);
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
-      const int m = mrow + RPT * i;
-      const bool pv = m < mend;
-      ar[i] = (pv && a_ok) ? *reinterpret_cast<const u32x4*>(p.a + (size_t)m * p.Cab + (size_t)a_ch0 * (16 / V))
-                           : zero4;
+      const bool pv = (mrow + RPT * i) < mend;
+      const unsigned oa = (pv && a_ok) ? ao32 + a_step * (unsigned)i : 0xfffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(la + (wvu + 4 * i) * 1024), 16, oa, 0, 0, 0);
       bool ok = pv && b_ok;
-      int hi = pho[i] * p.is + bdh, wi = pwo[i] * p.is + bdw;
+      int hi = hraw[i], wi = wraw[i];
       if (p.pad_mode == MT_PAD_REFLECT) {
         hi = hi < 0 ? -hi : hi;
         hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
@@ -347,32 +365,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       } else {
         ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
       }
-      const size_t off = (((size_t)pn[i] * p.Hi + hi) * p.Wi + wi) * p.Cbb + (size_t)bcq * 16;
-      br[i] = ok ? *reinterpret_cast<const u32x4*>(p.b + off) : zero4;
+      const unsigned pix = (unsigned)(nb[i] + __mul24(hi, p.Wi) + wi);
+      const unsigned ob = ok ? pix * (unsigned)p.Cbb + bcq16 : 0xfffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lb + (wvu + 4 * i) * 1024), 16, ob, 0, 0, 0);
       // advance this row's pixel by KP
-      pwo[i] += adv_w;
-      pho[i] += adv_h;
-      if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; pho[i]++; }
-      while (pho[i] >= p.Ho) { pho[i] -= p.Ho; pn[i]++; }
+      if (simple_adv) {
+        pwo[i] += adv_w; wraw[i] += adv_w_is;
+        if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; wraw[i] -= Wo_is; pho[i]++; hraw[i] += p.is; }
+        pho[i] += adv_h; hraw[i] += adv_h_is;
+        if (pho[i] >= p.Ho) { pho[i] -= p.Ho; hraw[i] -= Ho_is; nb[i] += HiWi; }
+      } else {
+        pwo[i] += adv_w; pho[i] += adv_h;
+        if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; pho[i]++; }
+        while (pho[i] >= p.Ho) { pho[i] -= p.Ho; nb[i] += HiWi; }
+        hraw[i] = pho[i] * p.is + bdh;
+        wraw[i] = pwo[i] * p.is + bdw;
+      }
     }
     mrow += KP;
+    ao32 += (unsigned)KP * (unsigned)p.Cab;
   };
-  // LDS image: row = pixel, swizzled so that the transposing / strided fragment reads are
-  // bank-conflict free (bf16: 32-byte slots XOR key(row); fp32: 64-byte slots XOR row&7).
   auto swz = [&](int prow, int c16) -> int {
     if constexpr (BF16) {
       const int key = (prow & 3) | ((prow >> 1) & 4);
       return prow * CPR + (c16 ^ (key << 1));
     } else {
       return prow * CPR + (c16 ^ ((prow & 7) << 2));
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NLD; i++) {
-      const int prow = rr + RPT * i;
-      sA[buf][swz(prow, cc)] = ar[i];
-      sB[buf][swz(prow, cc)] = br[i];
     }
   };
 
@@ -383,14 +401,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (mend - mbeg + KP - 1) / KP;
-  gload();
-  lstore(0);
-  __syncthreads();
+  issue(0);
 
   for (int ks = 0; ks < nk; ks++) {
     const int cur = ks & 1;
-    const bool more = (ks + 1) < nk;
-    if (more) gload();
+    __syncthreads();   // buffer `cur` landed (vmcnt(0) + barrier); buffer `cur^1` is free again
+    if (ks + 1 < nk) issue(cur ^ 1);
     if constexpr (BF16) {
       const char* bA = reinterpret_cast<const char*>(&sA[cur][0]);
       const char* bB = reinterpret_cast<const char*>(&sB[cur][0]);
@@ -441,13 +457,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
   }
 
-  // epilogue: D[row = a-channel (lane>>4)*4+j][col = lane&15]
+  // epilogue: D[row = a-channel (lane>>4)*4+j][col = lane&15] -> this split's own fp32 slab (plain stores;
+  // the splits are summed by unpack_kernel -- cheaper than 1.3 TB/s fp32 atomics at 20+ splits)
   const int fr = lane & 15, fg = lane >> 4;
   const int ncols = p.nchunks * V;
+  float* slab = p.out + (size_t)blockIdx.y * p.CaRows * ncols;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -458,14 +474,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       for (int b = 0; b < 4; b++) {
         const int col = bt * 128 + wbI * 64 + b * 16 + fr;
         if (col >= ncols) continue;
-        atomicAdd(p.out + (size_t)ca * ncols + col, acc[a][b][j]);
+        slab[(size_t)ca * ncols + col] = acc[a][b][j];
       }
     }
   }
 }
 
-int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s) {
-  MT_CHECK(p.ntaps <= 64, "wgrad: %d taps > 64", p.ntaps);
+int mt_launch_wgrad(int dtype, const WgradParams& pin, int nsplit, hipStream_t s) {
+  MT_CHECK(pin.ntaps <= 64, "wgrad: %d taps > 64", pin.ntaps);
+  MT_CHECK((double)pin.M * pin.Cab < 4294967000.0 && (double)pin.N * pin.Hi * pin.Wi * pin.Cbb < 4294967000.0,
+           "wgrad: operand exceeds 4 GiB (32-bit offsets)");
+  WgradParams p = pin;
+  p.a_bytes = (unsigned)((size_t)pin.M * pin.Cab);
+  p.b_bytes = (unsigned)((size_t)pin.N * pin.Hi * pin.Wi * pin.Cbb);
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int ncols = p.nchunks * V;
   dim3 grid(cdiv(p.CaRows, 128) * cdiv(ncols, 128), nsplit);
@@ -504,22 +525,33 @@ int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hi
   MT_LAUNCH_CHECK();
   return 0;
 }
-// dw[r*sr + c*sc + kh[t]*kW + kw[t]] = src[r][t][c]   (r<R, c<C; src rows have Cp columns)
-__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p) {
-  const long total = (long)p.R * p.ntaps * p.C;
+// dw[r*sr + c*sc + kh[t]*kW + kw[t]] = sum_split src[split][r][t][c]   (r<R, c<C; src rows have Cp columns)
+__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p, int nsplit,
+                              long slab) {
+  // one thread = 4 consecutive packed columns (16-byte reads from every split slab)
+  const int c4n = p.Cp >> 2;
+  const long total = (long)p.R * p.ntaps * c4n;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % p.C);
-    const long rt = i / p.C;
+    const int c4 = (int)(i % c4n);
+    const long rt = i / c4n;
     const int t = (int)(rt % p.ntaps);
     const int r = (int)(rt / p.ntaps);
-    dw[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]] = src[((long)r * p.ntaps + t) * p.Cp + c];
+    const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
+    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c4 * 4 + e;
+      if (c < p.C) d[(long)c * p.sc] = a[e];
+    }
   }
 }
-int mt_launch_unpack(const float* src, float* dw, const PackParams& p, hipStream_t s) {
-  const long total = (long)p.R * p.ntaps * p.C;
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, hipStream_t s) {
+  const long total = (long)p.R * p.ntaps * (p.Cp >> 2);
   if (total == 0) return 0;
   const int blocks = (int)min((long)4096, (total + 255) / 256);
-  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p);
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -35,7 +35,7 @@ struct IgemmParams {
 struct WgradParams {
   const char* a;   // pixel-major [M][Cab bytes]: its channels become output rows
   const char* b;   // gathered NHWC [N][Hi][Wi][Cbb bytes]: (tap, channel) become output columns
-  float* out;      // fp32 [CaRows][nchunks * V]; accumulated with atomics (caller zeroes)
+  float* out;      // fp32 [nsplit][CaRows][nchunks * V]: one slab per pixel split, summed by unpack_kernel
   int N, Hi, Wi;
   int Cab, Cbb;    // bytes per pixel
   unsigned a_bytes, b_bytes;  // tensor sizes in bytes (buffer-load range checks)
@@ -62,7 +62,7 @@ struct PackParams {
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
 int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
-int mt_launch_unpack(const float* src, float* dw, const PackParams& p, hipStream_t s);
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s);
