@@ -81,6 +81,10 @@ class Model(ABC, nn.Module):
 
     def init_scheduler(self):
         for opt in self.optimizer:
+            # resuming (last_iter >= 0): torch's schedulers require 'initial_lr'; the reference creates the
+            # scheduler BEFORE loading the optimizer checkpoint (model.py:47-52) and trips over exactly that
+            for group in self.optimizer[opt].param_groups:
+                group.setdefault("initial_lr", group["lr"])
             self.scheduler[opt] = get_scheduler(self.optimizer[opt], self.args, self.args.last_iter)
 
     def get_current_lr(self):
