@@ -37,15 +37,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
   return base + (b >> 3);
 }
 
-template <bool BF16, int WT>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  constexpr int PT = 128;                       // pixels per block tile
-  constexpr int WC = (WT >= 64) ? 64 : WT;      // wave tile: output channels
-  constexpr int WP = (WT == 128) ? 64 : 32;     // wave tile: pixels
+// Tile geometries (WT output channels x PT pixels per block, NT threads):
+//   <128,128,256>, <64,128,256>, <32,128,256>, <16,128,256>: 4 waves, wave tile up to 64x64, 2 blocks/CU
+//   <256,256,512>: 8 waves (2 x 4), wave tile 128 channels x 64 pixels, 128 KiB LDS, 1 block/CU -- 25 % fewer
+//   LDS fragment bytes per MFMA and the pixel tile is fetched once for all 256 output channels.
+template <bool BF16, int WT, int PT, int NT>
+__global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
+  constexpr int WC = (WT == 256) ? 128 : ((WT >= 64) ? 64 : WT);   // wave tile: output channels
+  constexpr int WP = (WT >= 128) ? 64 : 32;                        // wave tile: pixels
   constexpr int NWP = PT / WP;                  // waves along the pixel dimension
   constexpr int FC = WC / 16, FP = WP / 16;
   constexpr int SZ = BF16 ? 2 : 4;
-  constexpr int WLD = (WT * 8 + 255) / 256;     // weight-tile LDS-DMA instructions per wave per k-step
+  constexpr int RPP = NT / 8;                   // tile rows staged per pass of the whole block
+  constexpr int NXL = PT / RPP;                 // pixel-tile LDS-DMA instructions per wave per k-step
+  constexpr int WLD = (WT + RPP - 1) / RPP;     // weight-tile LDS-DMA instructions per wave per k-step
+
 
   __shared__ u32x4 sW[2][WT * 8];
   __shared__ u32x4 sX[2][PT * 8];
@@ -73,12 +79,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int c = (tid & 7) ^ (r0 & 7);
   const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HoWo = p.Ho * p.Wo;
-  int hb[4], wb[4];
-  unsigned ib[4];
+  int hb[NXL], wb[NXL];
+  unsigned ib[NXL];
   unsigned rvm = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int m = pt * PT + r0 + 32 * i;
+  for (int i = 0; i < NXL; i++) {
+    const int m = pt * PT + r0 + RPP * i;
     const bool rv = m < p.M;
     rvm |= (rv ? 1u : 0u) << i;
     const int mm = rv ? m : 0;
@@ -99,23 +105,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   unsigned wokm = 0;
 #pragma unroll
   for (int i = 0; i < WLD; i++) {
-    const int rl = r0 + 32 * i;
+    const int rl = r0 + RPP * i;
     const int row = wt * WT + rl;
     const bool ok = (rl < WT) && (row < p.CoRows);
     wokm |= (ok ? 1u : 0u) << i;
     wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)p.nchunks + (unsigned)c) * 16u;
   }
-  unsigned xo32[4];
+  static_assert(NXL == 4, "every geometry stages 4 pixel rows per thread");
+  unsigned xo32[4];   // (literal size: hipcc 7.2 drops the host stub when this lambda-captured array is NXL-sized)
   unsigned xokm = 0;
   auto retap = [&]() {
     xokm = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) xo32[i] = 0xfffffff0u;
+    for (int i = 0; i < NXL; i++) xo32[i] = 0xfffffff0u;
     if (tap < p.ntaps) {
       const int t = sTap[tap];
       const int dh = t >> 16, dw = (int)(short)(t & 0xffff);
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NXL; i++) {
         int hi = hb[i] + dh, wi = wb[i] + dw;
         bool ok = (rvm >> i) & 1u;
         if (p.pad_mode == MT_PAD_REFLECT) {
@@ -145,15 +152,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     char* lx = reinterpret_cast<char*>(&sX[buf][0]);
 #pragma unroll
     for (int i = 0; i < WLD; i++) {
-      if (wvu * 8 + 32 * i < WT) {
+      if (wvu * 8 + RPP * i < WT) {
         const unsigned o = (kin && ((wokm >> i) & 1u)) ? wo32[i] : 0xfffffff0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(lw + (wvu * 8 + 32 * i) * 128), 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(lw + (wvu * 8 + RPP * i) * 128), 16, o, 0, 0, 0);
       }
       wo32[i] += 128u;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(lx + (wvu * 8 + 32 * i) * 128), 16, xo32[i], 0, 0, 0);
+    for (int i = 0; i < NXL; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(lx + (wvu * 8 + RPP * i) * 128), 16, xo32[i], 0, 0, 0);
     // advance to the next k-step
     q += 8;
     const int otap = tap;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       retap();
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) xo32[i] += ((xokm >> i) & 1u) ? 128u : 0u;
+      for (int i = 0; i < NXL; i++) xo32[i] += ((xokm >> i) & 1u) ? 128u : 0u;
     }
   };
 
@@ -241,16 +248,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
 template <bool BF16>
 static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
-  const int nPT = cdiv(p.M, 128);
   if (p.M <= 0) return 0;
-  if (p.CoRows > 64) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 128>), dim3(nPT * cdiv(p.CoRows, 128)), dim3(256), 0, s, p);
+  const int nPT = cdiv(p.M, 128);
+  // big layers: 256x256 tiles when that gives at least ~one block per CU and no ragged channel tile
+  const int n256 = cdiv(p.M, 256) * (p.CoRows / 256);
+  if (p.CoRows % 256 == 0 && n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 256, 256, 512>), dim3(n256), dim3(512), 0, s, p);
+  } else if (p.CoRows > 64) {
+    hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(nPT * cdiv(p.CoRows, 128)), dim3(256), 0, s, p);
   } else if (p.CoRows > 32) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 64>), dim3(nPT), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
   } else if (p.CoRows > 16) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 32>), dim3(nPT), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 16>), dim3(nPT), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BF16, 16, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
   }
   MT_LAUNCH_CHECK();
   return 0;
@@ -265,11 +276,6 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   q.w_bytes = (unsigned)((size_t)p.CoRows * p.nchunks * 16);
   return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
 }
-static int unused_igemm_tail(int dtype, const IgemmParams& p, hipStream_t s) {
-  MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
-  return dtype == MT_BF16 ? launch_igemm_t<true>(p, s) : launch_igemm_t<false>(p, s);
-}
-
 // ------------------------------------------------------------------------------------------
 // weight gradient:  out[ca][tap][cb] += sum_pixels A[pixel][ca] * B[n, f(ho)+dh, f(wo)+dw, cb]
 // Both operands are pixel-major in memory, i.e. the reduction index is the slow one, so

@@ -59,6 +59,10 @@ CONV_CASES = [
     ("k3s1_wide", 2, 64, 20, 20, 160, 3, 1, 1, "reflect", False, "relu"),
     ("k3s1_256", 1, 256, 16, 16, 256, 3, 1, 1, "reflect", False, None),
     ("k3s2_zero_odd", 1, 24, 9, 11, 40, 3, 2, 1, "zero", True, None),
+    # large enough for the 256x256-tile kernel (Cout % 256 == 0, 256 pixel tiles): forward only hits it
+    ("k3s1_tile256_fwd", 4, 32, 128, 128, 256, 3, 1, 1, "reflect", True, "relu"),
+    # ... and with Cin = Cout = 256 the zero-padded data gradient does too (H*W*N = 65536 pixels)
+    ("k3s1_tile256_zero", 4, 256, 128, 128, 256, 3, 1, 1, "zero", False, None),
 ]
 
 
