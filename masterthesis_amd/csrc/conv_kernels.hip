@@ -9,6 +9,7 @@
 // (blocks.py:73) and their autograd backward.
 #include "mt_common.h"
 #include "conv_params.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // gather-GEMM:  Y[co][pixel] = sum_{tap, ci} Wp[co][tap][ci] * X[n, f(ho)+dh(tap), f(wo)+dw(tap), ci]
@@ -145,23 +146,27 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  // issue the asynchronous global->LDS copies of the next k-step into buffer `buf`
-  auto issue = [&](int buf) {
-    const bool kin = q < p.nchunks;
-    char* lw = reinterpret_cast<char*>(&sW[buf][0]);
-    char* lx = reinterpret_cast<char*>(&sX[buf][0]);
-#pragma unroll
-    for (int i = 0; i < WLD; i++) {
+  // The asynchronous global->LDS copies of the next k-step are issued ONE instruction at a time,
+  // interleaved with the MFMA groups of the current k-step (an LDS-DMA instruction costs ~60-180 issue
+  // cycles, MI355X_MICROARCH.md; a burst of 8 in front of the MFMAs leaves the matrix pipe idle).
+  // (the K tail needs no check on the weight side: there the pixel operand is zero -- tap >= ntaps -- and
+  // reading into the next pack row / past the end (range-checked -> 0) only multiplies finite weights by 0)
+  auto issue_piece = [&](int buf, int j) {           // j in [0, WLD + NXL)
+    if (j < WLD) {
+      const int i = j;
       if (wvu * 8 + RPP * i < WT) {
-        const unsigned o = (kin && ((wokm >> i) & 1u)) ? wo32[i] : 0xfffffff0u;
+        char* lw = reinterpret_cast<char*>(&sW[buf][0]);
+        const unsigned o = ((wokm >> i) & 1u) ? wo32[i] : 0xfffffff0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(lw + (wvu * 8 + RPP * i) * 128), 16, o, 0, 0, 0);
       }
       wo32[i] += 128u;
-    }
-#pragma unroll
-    for (int i = 0; i < NXL; i++)
+    } else if (j < WLD + NXL) {
+      const int i = j - WLD;
+      char* lx = reinterpret_cast<char*>(&sX[buf][0]);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(lx + (wvu * 8 + RPP * i) * 128), 16, xo32[i], 0, 0, 0);
-    // advance to the next k-step
+    }
+  };
+  auto issue_end = [&]() {                            // advance to the next k-step
     q += 8;
     const int otap = tap;
     tap += step_t;
@@ -173,6 +178,11 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < NXL; i++) xo32[i] += ((xokm >> i) & 1u) ? 128u : 0u;
     }
+  };
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < WLD + NXL; j++) issue_piece(buf, j);
+    issue_end();
   };
 
   f32x4 acc[FC][FP];
@@ -186,31 +196,56 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   retap();
   if (nk > 0) issue(0);
 
-  for (int ks = 0; ks < nk; ks++) {
-    const int cur = ks & 1;
+  // one k-step: MFMAs on buffer `cur`; if MORE, the copies of the next k-step go out one per MFMA group,
+  // all within the first half of the step so they have the second half to land before the next barrier
+  auto kstep = [&](int cur, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    constexpr int NPIECE = WLD + NXL;                 // DMA instructions of one k-step (<= 8)
     // drains this wave's LDS-DMA (vmcnt(0)) and joins the block: buffer `cur` is complete, and every wave
-    // has finished reading buffer `cur^1` (k-step ks-1), so it may be overwritten now
+    // has finished reading buffer `cur^1` (previous k-step), so it may be overwritten now
     __syncthreads();
-    if (ks + 1 < nk) issue(cur ^ 1);  // flies under this step's MFMAs
-#pragma unroll
-    for (int kc = 0; kc < 2; kc++) {
-      u32x4 wf[FC], xf[FP];
+    // Fragment reads: the 4-wave geometries have the registers to issue BOTH halves of the k-step up front
+    // (the second half's LDS latency hides under the first half's MFMAs); the 8-wave 256x256 geometry
+    // (128 accumulator VGPRs) reads each half right before its MFMAs.
+    constexpr int NB = (WT == 256) ? 1 : 2;
+    u32x4 wf[NB][FC], xf[NB][FP];
+    auto read_frags = [&](int kc, int slotb) {
 #pragma unroll
       for (int a = 0; a < FC; a++) {
         const int row = wcI * WC + a * 16 + fr;
-        wf[a] = sW[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
+        wf[slotb][a] = sW[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
       }
 #pragma unroll
       for (int b = 0; b < FP; b++) {
         const int row = wpI * WP + b * 16 + fr;
-        xf[b] = sX[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
+        xf[slotb][b] = sX[cur][row * 8 + ((kc * 4 + fg) ^ (row & 7))];
       }
+    };
+    if constexpr (NB == 2) { read_frags(0, 0); read_frags(1, 1); }
 #pragma unroll
-      for (int a = 0; a < FC; a++)
+    for (int kc = 0; kc < 2; kc++) {
+      if constexpr (NB == 1) read_frags(kc, 0);
+      const int fb = (NB == 2) ? kc : 0;
 #pragma unroll
-        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
+      for (int a = 0; a < FC; a++) {
+        const int slot = kc * FC + a;
+        if constexpr (MORE) {
+          if (FC >= 4) { if (slot < NPIECE) issue_piece(cur ^ 1, slot); }
+          else {
+#pragma unroll
+            for (int j = slot * 4; j < slot * 4 + 4; j++) if (j < NPIECE) issue_piece(cur ^ 1, j);
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[fb][a], xf[fb][b]);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
-  }
+    if constexpr (MORE) issue_end();
+  };
+  for (int ks = 0; ks + 1 < nk; ks++) kstep(ks & 1, std::true_type{});
+  if (nk > 0) kstep((nk - 1) & 1, std::false_type{});
 
   // ---- epilogue: bias + activation, packed NHWC store (4 consecutive channels per lane) ----
 #pragma unroll
