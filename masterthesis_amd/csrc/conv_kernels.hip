@@ -318,8 +318,10 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
 // ds_read_b64_tr_b16; the fp32 path needs one element per lane and uses ds_read_b32.
 // Split over pixel ranges (blockIdx.y) with fp32 atomic accumulation into `out`.
 // ------------------------------------------------------------------------------------------
-template <bool BF16>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+// REFLECT / SIMPLE are compile-time so the per-instruction address update in the k loop is straight-line
+// code (SIMPLE: a k-step of KP pixels wraps at most one image row and one image).
+template <bool BF16, bool REFLECT, bool SIMPLE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_kernel(const WgradParams p) {
   constexpr int KP = BF16 ? 64 : 32;       // pixels per k-step
   constexpr int V = BF16 ? 8 : 4;          // elements per 16-byte chunk
   constexpr int CPR = 128 / V;             // chunks per 128-element tile row (16 / 32)
@@ -333,9 +335,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int waI = wv >> 1, wbI = wv & 1;   // wave tile: 64 a-channels x 64 columns
 
+  // XCD-aware decode: blocks b, b+8, ... share an XCD (own L2).  All tiles of one pixel split stream the
+  // same dY / x rows, so each XCD gets a contiguous range of (split, tile) ids: the 18x re-read of the
+  // operands across tiles is then served by that XCD's L2 instead of the fabric.
   const int nAT = (p.CaRows + 127) / 128;
-  const int at = blockIdx.x % nAT, bt = blockIdx.x / nAT;
-  const int mbeg = blockIdx.y * p.mchunk;
+  const int ntiles = p.ntiles;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vid / ntiles, tile = vid - split * ntiles;
+  const int at = tile % nAT, bt = tile / nAT;
+  const int mbeg = split * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);   // host guarantees mbeg < mend for every split
 
   // staging coordinates.  LDS-DMA writes a wave's 64 x 16 B lane-linearly (4 bf16 / 2 fp32 tile rows per
@@ -378,7 +386,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
   const int adv_h = KP / p.Wo, adv_w = KP % p.Wo;
   const int adv_h_is = adv_h * p.is, adv_w_is = adv_w * p.is, Wo_is = p.Wo * p.is, Ho_is = p.Ho * p.is;
-  const bool simple_adv = HoWo >= KP;   // at most one row wrap and one image wrap per step
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -387,34 +394,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const unsigned a_step = (unsigned)RPT * (unsigned)p.Cab;
   const unsigned bcq16 = (unsigned)bcq * 16u;
 
-  // asynchronous global->LDS copies of the next KP pixels into buffer `buf`
-  auto issue = [&](int buf) {
-    char* la = reinterpret_cast<char*>(&sA[buf][0]);
-    char* lb = reinterpret_cast<char*>(&sB[buf][0]);
-#pragma unroll
-    for (int i = 0; i < NLD; i++) {
-      const bool pv = (mrow + RPT * i) < mend;
-      const unsigned oa = (pv && a_ok) ? ao32 + a_step * (unsigned)i : 0xfffffff0u;
+  // asynchronous global->LDS copies of the next KP pixels into buffer `buf`, one instruction per call
+  // (j = 2*row + {0: A operand, 1: B operand}) so they can be interleaved with the MFMA groups
+  auto issue_piece = [&](int buf, int j) {
+    const int i = j >> 1;
+    const bool pv = (mrow + RPT * i) < mend;
+    if ((j & 1) == 0) {
+      char* la = reinterpret_cast<char*>(&sA[buf][0]);
+      unsigned oa = ao32 + a_step * (unsigned)i;
+      oa = (pv && a_ok) ? oa : 0xfffffff0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(la + (wvu + 4 * i) * 1024), 16, oa, 0, 0, 0);
+    } else {
+      char* lb = reinterpret_cast<char*>(&sB[buf][0]);
       bool ok = pv && b_ok;
       int hi = hraw[i], wi = wraw[i];
-      if (p.pad_mode == MT_PAD_REFLECT) {
+      if constexpr (REFLECT) {
+        // branch-free reflection: |x| then (L-1) - |(L-1) - x|
         hi = hi < 0 ? -hi : hi;
-        hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
         wi = wi < 0 ? -wi : wi;
-        wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
+        const int th = (p.Hi - 1) - hi, tw = (p.Wi - 1) - wi;
+        hi = (p.Hi - 1) - (th < 0 ? -th : th);
+        wi = (p.Wi - 1) - (tw < 0 ? -tw : tw);
       } else {
         ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
       }
-      const unsigned pix = (unsigned)(nb[i] + __mul24(hi, p.Wi) + wi);
-      const unsigned ob = ok ? pix * (unsigned)p.Cbb + bcq16 : 0xfffffff0u;
+      unsigned ob = (unsigned)(nb[i] + __mul24(hi, p.Wi) + wi) * (unsigned)p.Cbb + bcq16;
+      ob = ok ? ob : 0xfffffff0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lb + (wvu + 4 * i) * 1024), 16, ob, 0, 0, 0);
-      // advance this row's pixel by KP
-      if (simple_adv) {
+      // advance this row's pixel by KP (select arithmetic, no divergent branches)
+      if constexpr (SIMPLE) {
         pwo[i] += adv_w; wraw[i] += adv_w_is;
-        if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; wraw[i] -= Wo_is; pho[i]++; hraw[i] += p.is; }
+        const bool c1 = pwo[i] >= p.Wo;
+        pwo[i] -= c1 ? p.Wo : 0; wraw[i] -= c1 ? Wo_is : 0; pho[i] += c1 ? 1 : 0; hraw[i] += c1 ? p.is : 0;
         pho[i] += adv_h; hraw[i] += adv_h_is;
-        if (pho[i] >= p.Ho) { pho[i] -= p.Ho; hraw[i] -= Ho_is; nb[i] += HiWi; }
+        const bool c2 = pho[i] >= p.Ho;
+        pho[i] -= c2 ? p.Ho : 0; hraw[i] -= c2 ? Ho_is : 0; nb[i] += c2 ? HiWi : 0;
       } else {
         pwo[i] += adv_w; pho[i] += adv_h;
         if (pwo[i] >= p.Wo) { pwo[i] -= p.Wo; pho[i]++; }
@@ -423,8 +437,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         wraw[i] = pwo[i] * p.is + bdw;
       }
     }
+  };
+  auto issue_end = [&]() {
     mrow += KP;
     ao32 += (unsigned)KP * (unsigned)p.Cab;
+  };
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2 * NLD; j++) issue_piece(buf, j);
+    issue_end();
   };
   auto swz = [&](int prow, int c16) -> int {
     if constexpr (BF16) {
@@ -444,10 +465,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int nk = (mend - mbeg + KP - 1) / KP;
   issue(0);
 
-  for (int ks = 0; ks < nk; ks++) {
-    const int cur = ks & 1;
+  auto kstep = [&](int cur, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
     __syncthreads();   // buffer `cur` landed (vmcnt(0) + barrier); buffer `cur^1` is free again
-    if (ks + 1 < nk) issue(cur ^ 1);
     if constexpr (BF16) {
       const char* bA = reinterpret_cast<const char*>(&sA[cur][0]);
       const char* bB = reinterpret_cast<const char*>(&sB[cur][0]);
@@ -471,12 +491,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
           bf[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++) {
+          // one LDS-DMA instruction of the next k-step per group of 4 MFMAs
+          if constexpr (more) issue_piece(cur ^ 1, kk * 4 + a);
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int b = 0; b < 4; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
       }
+      if constexpr (more) issue_end();
     } else {
+      if constexpr (more) issue(cur ^ 1);
       const float* fA = reinterpret_cast<const float*>(&sA[cur][0]);
       const float* fB = reinterpret_cast<const float*>(&sB[cur][0]);
       const int i16 = lane & 15, g = lane >> 4;
@@ -498,13 +525,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
     }
-  }
+  };
+  for (int ks = 0; ks + 1 < nk; ks++) kstep(ks & 1, std::true_type{});
+  kstep((nk - 1) & 1, std::false_type{});
 
   // epilogue: D[row = a-channel (lane>>4)*4+j][col = lane&15] -> this split's own fp32 slab (plain stores;
   // the splits are summed by unpack_kernel -- cheaper than 1.3 TB/s fp32 atomics at 20+ splits)
   const int fr = lane & 15, fg = lane >> 4;
   const int ncols = p.nchunks * V;
-  float* slab = p.out + (size_t)blockIdx.y * p.CaRows * ncols;
+  float* slab = p.out + (size_t)split * p.CaRows * ncols;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -530,11 +559,19 @@ int mt_launch_wgrad(int dtype, const WgradParams& pin, int nsplit, hipStream_t s
   p.b_bytes = (unsigned)((size_t)pin.N * pin.Hi * pin.Wi * pin.Cbb);
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int ncols = p.nchunks * V;
-  dim3 grid(cdiv(p.CaRows, 128) * cdiv(ncols, 128), nsplit);
-  if (dtype == MT_BF16)
-    hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, p);
+  p.ntiles = cdiv(p.CaRows, 128) * cdiv(ncols, 128);
+  dim3 grid(p.ntiles * nsplit);
+  const int KP = dtype == MT_BF16 ? 64 : 32;
+  const bool refl = p.pad_mode == MT_PAD_REFLECT, simple = p.Ho * p.Wo >= KP;
+#define MT_WG(B, R, S) hipLaunchKernelGGL((wgrad_kernel<B, R, S>), grid, dim3(256), 0, s, p)
+  if (dtype == MT_BF16) {
+    if (refl) { if (simple) MT_WG(true, true, true); else MT_WG(true, true, false); }
+    else { if (simple) MT_WG(true, false, true); else MT_WG(true, false, false); }
+  } else {
+    if (refl) { if (simple) MT_WG(false, true, true); else MT_WG(false, true, false); }
+    else { if (simple) MT_WG(false, false, true); else MT_WG(false, false, false); }
+  }
+#undef MT_WG
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -45,6 +45,7 @@ struct WgradParams {
   int ntaps, cpc, nchunks;
   int pad_mode;
   int mchunk;      // pixels per split
+  int ntiles;      // output tiles (128x128) per split; grid = ntiles * nsplit blocks
   short dh[MT_MAX_TAPS];
   short dw[MT_MAX_TAPS];
 };
