@@ -109,7 +109,17 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
                         const float* bias, int nbias, void* out, int Hd, int Wd, int Cout_p, int e, int act,
                         hipStream_t s) {
   const int sz = esz(d->dtype), V = vec(d->dtype), st = d->stride;
-  const char* wp = (const char*)pack;
+  MT_CHECK(st * st <= MT_MAX_PHASES, "conv: stride %d has too many phases", st);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)in; p.w = (const char*)pack; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
+  p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
+  p.Co = Cout_p; p.CoRows = Cout_p;
+  p.Hout = Hd; p.Wout = Wd; p.os = st; p.is = 1;
+  p.cpc = Cin_p / V;
+  p.pad_mode = MT_PAD_ZERO; p.act = act; p.slope = d->slope;
+  size_t w_off = 0;
+  int tap0 = 0;
   for (int ph = 0; ph < st; ph++)
     for (int pw = 0; pw < st; pw++) {
       short kh[MT_MAX_TAPS], kw[MT_MAX_TAPS];
@@ -117,23 +127,19 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
       const int o0h = posmod(ph - e, st), o0w = posmod(pw - e, st);
       const int Hg = o0h < Hd ? (Hd - o0h + st - 1) / st : 0;
       const int Wg = o0w < Wd ? (Wd - o0w + st - 1) / st : 0;
-      IgemmParams p;
-      memset(&p, 0, sizeof(p));
-      p.x = (const char*)in; p.w = wp; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
-      p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
-      p.Ho = Hg; p.Wo = Wg; p.M = d->N * Hg * Wg;
-      p.Co = Cout_p; p.CoRows = Cout_p;
-      p.Hout = Hd; p.Wout = Wd; p.os = st; p.oh0 = o0h; p.ow0 = o0w; p.is = 1;
-      p.ntaps = nt; p.cpc = Cin_p / V; p.nchunks = nt * p.cpc;
-      p.pad_mode = MT_PAD_ZERO; p.act = act; p.slope = d->slope;
+      IgemmPhase& q = p.ph[p.nphase];
+      q.w_off = (unsigned)w_off; q.ntaps = nt; q.tap0 = tap0;
+      q.Ho = Hg; q.Wo = Wg; q.M = d->N * Hg * Wg; q.oh0 = o0h; q.ow0 = o0w;
       for (int t = 0; t < nt; t++) {
-        p.dh[t] = (short)((o0h + e - kh[t]) / st);
-        p.dw[t] = (short)((o0w + e - kw[t]) / st);
+        p.dh[tap0 + t] = (short)((o0h + e - kh[t]) / st);
+        p.dw[tap0 + t] = (short)((o0w + e - kw[t]) / st);
       }
-      if (p.M > 0 && mt_launch_igemm(d->dtype, p, s)) return 2;
-      wp += (size_t)Cout_p * nt * Cin_p * sz;
+      tap0 += nt;
+      w_off += (size_t)Cout_p * nt * Cin_p * sz;
+      if (q.M > 0) p.nphase++;   // an empty phase (no output pixels) is dropped; a phase without taps writes zeros
     }
-  return 0;
+  if (p.nphase == 0) return 0;
+  return mt_launch_igemm(d->dtype, p, s);
 }
 
 // gather-form launch shared by Conv2d fwd and ConvTranspose2d bwd_data.
@@ -146,11 +152,13 @@ static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, 
   memset(&p, 0, sizeof(p));
   p.x = (const char*)in; p.w = (const char*)pack; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
   p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
-  p.Ho = Hg; p.Wo = Wg; p.M = d->N * Hg * Wg;
   p.Co = Cout_p; p.CoRows = Cout_p;
-  p.Hout = Hg; p.Wout = Wg; p.os = 1; p.oh0 = 0; p.ow0 = 0; p.is = d->stride;
-  p.ntaps = d->kh * d->kw; p.cpc = Cin_p / V; p.nchunks = p.ntaps * p.cpc;
+  p.Hout = Hg; p.Wout = Wg; p.os = 1; p.is = d->stride;
+  p.cpc = Cin_p / V;
   p.pad_mode = pad_mode; p.act = act; p.slope = d->slope;
+  p.nphase = 1;
+  IgemmPhase& q = p.ph[0];
+  q.w_off = 0; q.ntaps = d->kh * d->kw; q.tap0 = 0; q.Ho = Hg; q.Wo = Wg; q.M = d->N * Hg * Wg; q.oh0 = 0; q.ow0 = 0;
   for (int a = 0; a < d->kh; a++)
     for (int b = 0; b < d->kw; b++) {
       p.dh[a * d->kw + b] = (short)(a - d->pad);

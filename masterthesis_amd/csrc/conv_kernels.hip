@@ -63,10 +63,19 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const int fr = lane & 15, fg = lane >> 4;
   const int wcI = wv / NWP, wpI = wv % NWP;
 
-  if (tid < 64) sTap[tid] = tid < p.ntaps ? (((int)p.dh[tid] << 16) | ((int)p.dw[tid] & 0xffff)) : 0;
-
   const int nWT = (p.CoRows + WT - 1) / WT;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int phi = 0;
+  for (int i = 1; i < p.nphase; i++) phi = (wg >= p.ph[i].blk0) ? i : phi;
+  const IgemmPhase& ph = p.ph[phi];
+  const int ph_ntaps = ph.ntaps, ph_Ho = ph.Ho, ph_Wo = ph.Wo, ph_M = ph.M;
+  const int ph_nchunks = ph_ntaps * p.cpc;
+  const char* const ph_w = p.w + ph.w_off;
+  wg -= ph.blk0;
+  if (tid < 64) {
+    const int t = ph.tap0 + tid;
+    sTap[tid] = tid < ph_ntaps ? (((int)p.dh[t] << 16) | ((int)p.dw[t] & 0xffff)) : 0;
+  }
   const int wt = wg % nWT, pt = wg / nWT;
 
   // ---- per-thread staging coordinates (fixed over the k loop) ----
@@ -79,20 +88,20 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const int r0 = tid >> 3;
   const int c = (tid & 7) ^ (r0 & 7);
   const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int HoWo = p.Ho * p.Wo;
+  const int HoWo = ph_Ho * ph_Wo;
   int hb[NXL], wb[NXL];
   unsigned ib[NXL];
   unsigned rvm = 0;
 #pragma unroll
   for (int i = 0; i < NXL; i++) {
     const int m = pt * PT + r0 + RPP * i;
-    const bool rv = m < p.M;
+    const bool rv = m < ph_M;
     rvm |= (rv ? 1u : 0u) << i;
     const int mm = rv ? m : 0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
+    const int ho = rem / ph_Wo;
+    const int wo = rem - ho * ph_Wo;
     hb[i] = ho * p.is;
     wb[i] = wo * p.is;
     ib[i] = (unsigned)n * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
     const int row = wt * WT + rl;
     const bool ok = (rl < WT) && (row < p.CoRows);
     wokm |= (ok ? 1u : 0u) << i;
-    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)p.nchunks + (unsigned)c) * 16u;
+    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)ph_nchunks + (unsigned)c) * 16u;
   }
   static_assert(NXL == 4, "every geometry stages 4 pixel rows per thread");
   unsigned xo32[4];   // (literal size: hipcc 7.2 drops the host stub when this lambda-captured array is NXL-sized)
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
     xokm = 0;
 #pragma unroll
     for (int i = 0; i < NXL; i++) xo32[i] = 0xfffffff0u;
-    if (tap < p.ntaps) {
+    if (tap < ph_ntaps) {
       const int t = sTap[tap];
       const int dh = t >> 16, dw = (int)(short)(t & 0xffff);
 #pragma unroll
@@ -144,7 +153,8 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   };
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, (unsigned)p.CoRows * (unsigned)ph_nchunks * 16u, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   // The asynchronous global->LDS copies of the next k-step are issued ONE instruction at a time,
   // interleaved with the MFMA groups of the current k-step (an LDS-DMA instruction costs ~60-180 issue
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.nchunks + 7) >> 3;
+  const int nk = (ph_nchunks + 7) >> 3;
   __syncthreads();  // sTap visible
   retap();
   if (nk > 0) issue(0);
@@ -251,12 +261,12 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
   for (int b = 0; b < FP; b++) {
     const int m = pt * PT + wpI * WP + b * 16 + fr;
-    if (m >= p.M) continue;
+    if (m >= ph_M) continue;
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    const int oh = ho * p.os + p.oh0, ow = wo * p.os + p.ow0;
+    const int ho = rem / ph_Wo;
+    const int wo = rem - ho * ph_Wo;
+    const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
     if ((unsigned)oh >= (unsigned)p.Hout || (unsigned)ow >= (unsigned)p.Wout) continue;
     char* yp = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
 #pragma unroll
@@ -282,35 +292,43 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 }
 
 template <bool BF16>
-static int launch_igemm_t(const IgemmParams& p, hipStream_t s) {
-  if (p.M <= 0) return 0;
-  const int nPT = cdiv(p.M, 128);
-  // big layers: 256x256 tiles when that gives at least ~one block per CU and no ragged channel tile
-  const int n256 = cdiv(p.M, 256) * (p.CoRows / 256);
-  if (p.CoRows % 256 == 0 && n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 256, 256, 512>), dim3(n256), dim3(512), 0, s, p);
-  } else if (p.CoRows > 64) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(nPT * cdiv(p.CoRows, 128)), dim3(256), 0, s, p);
-  } else if (p.CoRows > 32) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
-  } else if (p.CoRows > 16) {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((igemm_kernel<BF16, 16, 128, 256>), dim3(nPT), dim3(256), 0, s, p);
+static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
+  // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
+  int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
+  if (p.nphase == 1 && p.CoRows % 256 == 0) {
+    const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
+    if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
   }
+  int total = 0;
+  for (int i = 0; i < p.nphase; i++) {
+    p.ph[i].blk0 = total;
+    p.ph[i].nblk = cdiv(p.ph[i].M, PT) * cdiv(p.CoRows, WT);
+    total += p.ph[i].nblk;
+  }
+  if (total == 0) return 0;
+  if (WT == 256) hipLaunchKernelGGL((igemm_kernel<BF16, 256, 256, 512>), dim3(total), dim3(512), 0, s, p);
+  else if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
+  else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);
+  else if (WT == 32) hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(total), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((igemm_kernel<BF16, 16, 128, 256>), dim3(total), dim3(256), 0, s, p);
   MT_LAUNCH_CHECK();
   return 0;
 }
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
-  MT_CHECK(p.ntaps <= 64, "igemm: %d taps > 64", p.ntaps);
+  MT_CHECK(p.nphase >= 1 && p.nphase <= MT_MAX_PHASES, "igemm: bad phase count %d", p.nphase);
+  MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
   MT_CHECK((double)p.N * p.Hi * p.Wi * p.Cib < 4294967000.0, "igemm: input tensor exceeds 4 GiB (32-bit offsets)");
-  MT_CHECK((double)p.CoRows * p.nchunks * 16.0 < 4294967000.0, "igemm: weight pack exceeds 4 GiB");
+  double wbytes = 0;
+  int taps = 0;
+  for (int i = 0; i < p.nphase; i++) { wbytes += (double)p.CoRows * p.ph[i].ntaps * p.cpc * 16.0; taps += p.ph[i].ntaps; }
+  MT_CHECK(wbytes < 4294967000.0, "igemm: weight pack exceeds 4 GiB");
+  MT_CHECK(taps <= MT_MAX_TAPS, "igemm: %d taps > %d", taps, MT_MAX_TAPS);
   IgemmParams q = p;
   q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
-  q.w_bytes = (unsigned)((size_t)p.CoRows * p.nchunks * 16);
   return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
 }
+
 // ------------------------------------------------------------------------------------------
 // weight gradient:  out[ca][tap][cb] += sum_pixels A[pixel][ca] * B[n, f(ho)+dh, f(wo)+dw, cb]
 // Both operands are pixel-major in memory, i.e. the reduction index is the slow one, so

@@ -6,6 +6,20 @@
 
 #define MT_MAX_TAPS 64
 
+#define MT_MAX_PHASES 16
+
+// One sub-problem of a launch.  Gather-form convolutions have one; the scatter form (stride-s data
+// gradient / transposed conv) has s*s sub-pixel phases that differ in their tap subset, weight slice and
+// output offset.  All phases run in ONE launch (blocks [blk0, blk0+nblk) belong to a phase), so the
+// dispatcher balances them instead of paying a ragged last round of blocks per phase.
+struct IgemmPhase {
+  unsigned w_off;     // byte offset of this phase's weight pack
+  int ntaps, tap0;    // taps [tap0, tap0+ntaps) of the dh/dw tables
+  int Ho, Wo, M;      // GEMM pixel grid of the phase, M = N*Ho*Wo
+  int oh0, ow0;       // output pixel = (ho*os + oh0, wo*os + ow0)
+  int blk0, nblk;     // filled by the launcher for the chosen tile geometry
+};
+
 struct IgemmParams {
   const char* x;      // gathered operand, NHWC [N][Hi][Wi][Cib bytes]
   const char* w;      // packed weights [CoRows][nchunks * 16 bytes]
@@ -15,16 +29,15 @@ struct IgemmParams {
   int Cib;            // bytes per input pixel (padded channels * element size)
   unsigned x_bytes;   // size of the input tensor / weight pack in bytes (hardware range check of the
   unsigned w_bytes;   // buffer loads: out-of-range lanes read zeros -> zero padding costs no branch)
-  int Ho, Wo, M;      // GEMM pixel grid, M = N*Ho*Wo
   int Co;             // padded output channels (elements per output pixel)
   int CoRows;         // rows of the weight pack (== Co)
   int nbias;
   int Hout, Wout;     // output tensor spatial size
-  int os, oh0, ow0;   // output pixel = (ho*os + oh0, wo*os + ow0); out-of-range pixels are skipped
+  int os;             // output pixel stride (see IgemmPhase); out-of-range pixels are skipped
   int is;             // input base coordinate = ho*is (+ dh[tap])
-  int ntaps;
   int cpc;            // 16-byte chunks per tap
-  int nchunks;        // ntaps * cpc
+  int nphase;
+  IgemmPhase ph[MT_MAX_PHASES];
   int pad_mode;
   int act;
   float slope;
