@@ -73,9 +73,11 @@ size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d);
 int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx,
                      void* ws, size_t ws_bytes, mt_stream_t s);
 size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
-/* dw (reference layout, fp32, overwritten), dbias (fp32 [Co], overwritten; may be NULL). */
+/* dw (reference layout, fp32), dbias (fp32 [Co]; may be NULL).  accumulate == 0: both are overwritten;
+ * accumulate != 0: the gradients are ADDED to their current contents (lets the caller point dw/dbias at
+ * the parameter's .grad and skip a separate accumulation pass). */
 int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw,
-                       float* dbias, void* ws, size_t ws_bytes, mt_stream_t s);
+                       float* dbias, void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
 
 /* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
 int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,

@@ -230,7 +230,7 @@ extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
 }
 
 extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
-                                  void* ws, size_t ws_bytes, mt_stream_t st) {
+                                  void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
   if (check_desc(d)) return 1;
   hipStream_t s = (hipStream_t)st;
   MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_weight_ws_bytes(d), "conv_bwd_weight: workspace too small");
@@ -269,10 +269,12 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   const int ncols = p.nchunks * V;
   int nsplit;
   wgrad_split(d, p.M, &nsplit, &p.mchunk);
-  if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
-  if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, s)) return 2;
+  if (dw != nullptr) {
+    if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
+    if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, accumulate, s)) return 2;
+  }
   if (dbias != nullptr) {
-    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, s)) return 2;
+    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, accumulate, s)) return 2;
   }
   return 0;
 }

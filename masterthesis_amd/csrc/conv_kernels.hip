@@ -623,7 +623,7 @@ int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hi
 }
 // dw[r*sr + c*sc + kh[t]*kW + kw[t]] = sum_split src[split][r][t][c]   (r<R, c<C; src rows have Cp columns)
 __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p, int nsplit,
-                              long slab) {
+                              long slab, int accumulate) {
   // one thread = 4 consecutive packed columns (16-byte reads from every split slab)
   const int c4n = p.Cp >> 2;
   const long total = (long)p.R * p.ntaps * c4n;
@@ -639,15 +639,19 @@ __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int c = c4 * 4 + e;
-      if (c < p.C) d[(long)c * p.sc] = a[e];
+      if (c < p.C) {
+        float* o = d + (long)c * p.sc;
+        *o = accumulate ? *o + a[e] : a[e];
+      }
     }
   }
 }
-int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, hipStream_t s) {
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
+                     hipStream_t s) {
   const long total = (long)p.R * p.ntaps * (p.Cp >> 2);
   if (total == 0) return 0;
   const int blocks = (int)min((long)4096, (total + 255) / 256);
-  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab);
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -742,11 +746,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ d
     }
   }
 }
-int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s) {
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, hipStream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(cchunks <= 256, "colsum: too many channels %d", Cp);
-  if (hipMemsetAsync(db, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("colsum memset failed"); return 2; }
+  if (!accumulate && hipMemsetAsync(db, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("colsum memset failed"); return 2; }
   if (npix == 0) return 0;
   const int threads = 256;
   const int npl = threads / cchunks;

@@ -76,7 +76,8 @@ struct PackParams {
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
 int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
-int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, hipStream_t s);
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
+                     hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
-int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, hipStream_t s);
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, hipStream_t s);

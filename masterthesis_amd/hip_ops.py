@@ -154,6 +154,14 @@ def _get_pack(owner, weight, desc, which):
 # optional HIP-event timing of selected forward-conv launches (used by bench.py's roofline leg)
 # --------------------------------------------------------------------------------------
 _KTIMER = {"match": None, "events": []}
+_FUSE_WGRAD_ACC = [False]
+
+
+def set_fused_grad_accumulation(on):
+    """When on, conv weight/bias gradients are ADDED straight into ``param.grad`` by the wgrad epilogue
+    (no temporary + torch add); autograd then receives None for them.  Requires ``param.grad`` to exist
+    (FusedAdam's flat gradient views) -- only valid for ``loss.backward()`` style training."""
+    _FUSE_WGRAD_ACC[0] = bool(on)
 
 
 def kernel_timer_start(match):
@@ -209,6 +217,7 @@ class _Conv(torch.autograd.Function):
             _KTIMER["events"].append((e0, e1, N))
         ctx.desc = desc
         ctx.owner = owner
+        ctx.bias_owner = bias
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         return y
@@ -237,13 +246,24 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1] or want_b:
             nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
             ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
-            dw = torch.empty_like(weight)
-            if want_b:
-                db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
-            L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
-                                           _stream()), "mt_conv_bwd_weight")
-            if not ctx.needs_input_grad[1]:
-                dw = None
+
+            def fused_target(p):
+                g = None if p is None else p.grad
+                ok = (_FUSE_WGRAD_ACC[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+                      and g.shape == p.shape and g.is_cuda)
+                return g if ok else None
+            gw = fused_target(ctx.owner) if ctx.needs_input_grad[1] else None
+            gb = fused_target(ctx.bias_owner) if want_b else None
+            if gw is not None and (gb is not None or not want_b):
+                # accumulate in place; autograd gets None for both
+                L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), _ptr(ws), nws, 1,
+                                               _stream()), "mt_conv_bwd_weight")
+            else:
+                dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+                if want_b:
+                    db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
+                L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, 0,
+                                               _stream()), "mt_conv_bwd_weight")
         return dx, dw, db, None
 
 

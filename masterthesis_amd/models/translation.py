@@ -66,6 +66,8 @@ class TranslationModel(Model):
         if args.vgg_loss is not None:
             raise NotImplementedError("--vgg_loss needs downloaded VGG weights; out of scope")
         self.print_loss = ["g_adv", "g_cls", "l1_cc_rec"]
+        # conv weight gradients are accumulated straight into FusedAdam's flat gradient views
+        ops.set_fused_grad_accumulation(True)
 
     # ---- small helpers -------------------------------------------------------------------------
     def get_z_random(self, bs, latent_dim):

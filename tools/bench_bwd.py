@@ -18,7 +18,7 @@ def run(name, N, Ci, H, W, Co, k, stride, pad, mode, iters=30):
     n1 = lib.mt_conv_bwd_data_ws_bytes(C.byref(d)); ws1 = torch.empty(max(n1, 16), dtype=torch.uint8, device=dev)
     n2 = lib.mt_conv_bwd_weight_ws_bytes(C.byref(d)); ws2 = torch.empty(n2, dtype=torch.uint8, device=dev)
     def fd(): lib.mt_conv_bwd_data(C.byref(d), C.c_void_p(dy.data_ptr()), C.c_void_p(pk.data_ptr()), C.c_void_p(dx.data_ptr()), C.c_void_p(ws1.data_ptr()), n1, s)
-    def fw(): lib.mt_conv_bwd_weight(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), None, C.c_void_p(ws2.data_ptr()), n2, s)
+    def fw(): lib.mt_conv_bwd_weight(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), None, C.c_void_p(ws2.data_ptr()), n2, 0, s)
     def t(fn):
         for _ in range(3): fn()
         torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
