@@ -646,12 +646,47 @@ __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__
     }
   }
 }
+// Fast path (sc == ntaps, natural tap order -- every weight-gradient unpack): for a fixed row r the output
+// [c][kh][kw] is one contiguous run, so a block sums the split slabs for 64 columns with coalesced reads,
+// transposes [t][c] -> [c][t] through LDS and writes a contiguous run.
+__global__ __launch_bounds__(256) void unpack_t_kernel(const float* __restrict__ src, float* __restrict__ dw,
+                                                       PackParams p, int nsplit, long slab, int accumulate) {
+  __shared__ float tile[64 * MT_MAX_TAPS + 64];
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, nt = p.ntaps;
+  const int ncl = min(64, p.Cp - c0);
+  const float* base = src + ((long)r * nt) * p.Cp + c0;
+  for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
+    const int t = idx >> 6, cl = idx & 63;
+    float a = 0.f;
+    if (cl < ncl) {
+      const float* q = base + (long)t * p.Cp + cl;
+      for (int k = 0; k < nsplit; k++) a += q[(long)k * slab];
+    }
+    tile[cl * nt + t + (cl >> 5)] = a;      // +1 float of padding per 32 columns against bank conflicts
+  }
+  __syncthreads();
+  const int nvalid = min(64, p.C - c0);
+  float* out = dw + (long)r * p.sr + (long)c0 * nt;
+  for (int idx = threadIdx.x; idx < nvalid * nt; idx += 256) {
+    const int cl = idx / nt;
+    const float v = tile[idx + (cl >> 5)];
+    out[idx] = accumulate ? out[idx] + v : v;
+  }
+}
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s) {
   const long total = (long)p.R * p.ntaps * (p.Cp >> 2);
   if (total == 0) return 0;
-  const int blocks = (int)min((long)4096, (total + 255) / 256);
-  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  bool natural = (p.sc == p.ntaps);
+  for (int t = 0; t < p.ntaps && natural; t++) natural = (p.kh[t] * p.kW + p.kw[t] == t);
+  // the transposing kernel needs enough (row, 64-column) blocks to fill the chip; tiny weight tensors with
+  // many splits keep the element-parallel kernel
+  if (natural && nsplit <= 4 && (long)p.R * cdiv(p.Cp, 64) >= 512) {
+    hipLaunchKernelGGL(unpack_t_kernel, dim3(p.R, cdiv(p.Cp, 64)), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  } else {
+    const int blocks = (int)min((long)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  }
   MT_LAUNCH_CHECK();
   return 0;
 }
