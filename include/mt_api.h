@@ -68,6 +68,12 @@ int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, m
 /* y = act(conv(x) + bias).  bias may be NULL (length Co, fp32). */
 int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                 void* y, mt_stream_t s);
+/* Forward with the normalisation statistics of the output fused into the GEMM epilogue:
+ * stats [N][Cp][2] = {sum, sum of squares} over H*W per (image, channel) -- the mt_nc_stats() result, so
+ * the InstanceNorm/AdaIN/LayerNorm that follows (blocks.py:38-42,158-164) skips its statistics pass.
+ * d->act must be MT_ACT_NONE; the caller passes stats ZERO-FILLED (the epilogue accumulates into it). */
+int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
+                      void* y, float* stats, mt_stream_t s);
 size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d);
 /* dx = conv_bwd_data(dy).  dy is the gradient w.r.t. the pre-activation output. */
 int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx,

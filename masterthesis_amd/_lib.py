@@ -41,6 +41,7 @@ SIGNATURES = {
     "mt_conv_pack_bytes": (_z, [_dp, _i]),
     "mt_conv_pack": (_i, [_dp, _i, _p, _p, _p]),
     "mt_conv_fwd": (_i, [_dp, _p, _p, _p, _p, _p]),
+    "mt_conv_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _p, _p]),
     "mt_conv_bwd_data_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_data": (_i, [_dp, _p, _p, _p, _p, _z, _p]),
     "mt_conv_bwd_weight_ws_bytes": (_z, [_dp]),

@@ -146,11 +146,12 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
 //   out[o] = sum_k in[o*stride - pad + k] * W[k]
 static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
                        const float* bias, int nbias, void* out, int Hg, int Wg, int Cout_p, int pad_mode, int act,
-                       hipStream_t s) {
+                       hipStream_t s, float* stats = nullptr) {
   const int sz = esz(d->dtype), V = vec(d->dtype);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)in; p.w = (const char*)pack; p.bias = bias; p.nbias = nbias; p.y = (char*)out;
+  p.stats = stats;
   p.N = d->N; p.Hi = Hin; p.Wi = Win; p.Cib = Cin_p * sz;
   p.Co = Cout_p; p.CoRows = Cout_p;
   p.Hout = Hg; p.Wout = Wg; p.os = 1; p.is = d->stride;
@@ -177,6 +178,29 @@ extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pac
   if (!d->transposed)
     return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s);
   return scatter_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad, d->act, s);
+}
+
+extern "C" int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);
+
+// Forward + per-(image, channel) {sum, sum^2} of the output (the InstanceNorm / AdaIN / LayerNorm
+// statistics pass).  Fused into the GEMM epilogue when a wave's pixels cannot straddle two images;
+// otherwise the separate statistics kernel runs.  stats: fp32 [N][Cop][2], MUST BE ZERO on entry (the
+// epilogue accumulates with atomics).
+extern "C" int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
+                                 void* y, float* stats, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  MT_CHECK(stats != nullptr, "conv_fwd_stats: null stats");
+  MT_CHECK(d->act == MT_ACT_NONE, "conv_fwd_stats: statistics are taken of the conv output, activation must be none");
+  hipStream_t s = (hipStream_t)st;
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  const bool fuse = !d->transposed && ((Ho * Wo) % 256 == 0);   // a block's pixel tile stays inside one image
+  if (!fuse) {
+    if (mt_conv_fwd(d, x, pack_fwd, bias, y, st)) return 2;
+    return mt_nc_stats(d->dtype, y, stats, d->N, Ho * Wo, Cop, st);
+  }
+  return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, stats);
 }
 
 extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {

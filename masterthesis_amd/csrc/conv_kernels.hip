@@ -258,34 +258,81 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   if (nk > 0) kstep((nk - 1) & 1, std::false_type{});
 
   // ---- epilogue: bias + activation, packed NHWC store (4 consecutive channels per lane) ----
+  // per pixel fragment: output address (or null when the pixel is outside the problem / output)
+  char* yp[FP];
 #pragma unroll
   for (int b = 0; b < FP; b++) {
     const int m = pt * PT + wpI * WP + b * 16 + fr;
-    if (m >= ph_M) continue;
-    const int n = m / HoWo;
-    const int rem = m - n * HoWo;
-    const int ho = rem / ph_Wo;
-    const int wo = rem - ho * ph_Wo;
-    const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
-    if ((unsigned)oh >= (unsigned)p.Hout || (unsigned)ow >= (unsigned)p.Wout) continue;
-    char* yp = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
+    yp[b] = nullptr;
+    if (m < ph_M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / ph_Wo;
+      const int wo = rem - ho * ph_Wo;
+      const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
+      if ((unsigned)oh < (unsigned)p.Hout && (unsigned)ow < (unsigned)p.Wout)
+        yp[b] = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
+    }
+  }
+  // fused InstanceNorm statistics (p.stats != null): all PT pixels of the block lie in ONE image (host
+  // guarantees Ho*Wo % 256 == 0).  Sum over the wave's pixel fragments in registers, over the 16 pixel lanes
+  // with xor-shuffles, over the block's pixel waves through LDS (the weight tile buffer is free now), then ONE
+  // full-width fp32 atomic instruction per 64 (channel, moment) pairs -- 4-lane atomics issued per wave
+  // and channel cost ~25 us per launch at one atomic instruction per ~50 ns per CU.
+  const bool do_stats = p.stats != nullptr;
+  float* red = reinterpret_cast<float*>(&sW[0][0]);     // [NWP][WT][2]
+  if (do_stats) __syncthreads();                        // every wave is done reading the last weight tile
 #pragma unroll
-    for (int a = 0; a < FC; a++) {
-      const int co = wt * WT + wcI * WC + a * 16 + fg * 4;
-      if (co >= p.Co) continue;
+  for (int a = 0; a < FC; a++) {
+    const int col = wcI * WC + a * 16 + fg * 4;         // channel within the block tile
+    const int co = wt * WT + col;
+    if (co >= p.Co) continue;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bv[j] = (p.bias != nullptr && (co + j) < p.nbias) ? p.bias[co + j] : 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < FP; b++) {
+      if (yp[b] == nullptr) continue;
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float t = acc[a][b][j];
-        if (p.bias != nullptr && (co + j) < p.nbias) t += p.bias[co + j];
-        v[j] = act_apply(t, p.act, p.slope);
+        v[j] = act_apply(acc[a][b][j] + bv[j], p.act, p.slope);
+        s1[j] += v[j];
+        s2[j] += v[j] * v[j];
       }
       if constexpr (BF16) {
         u32x2 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(yp + (size_t)co * 2) = o;
+        *reinterpret_cast<u32x2*>(yp[b] + (size_t)co * 2) = o;
       } else {
         f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(yp + (size_t)co * 4) = o;
+        *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = o;
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float t1 = row16_sum(s1[j]), t2 = row16_sum(s2[j]);
+        if (fr == 0) {
+          red[((wpI * WT) + col + j) * 2] = t1;
+          red[((wpI * WT) + col + j) * 2 + 1] = t2;
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    const int m0 = pt * PT;
+    if (m0 < ph_M) {
+      const int n0 = m0 / HoWo;
+      for (int idx = tid; idx < WT * 2; idx += NT) {
+        const int col = idx >> 1;
+        if (wt * WT + col < p.Co) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < NWP; w++) t += red[(w * WT + col) * 2 + (idx & 1)];
+          atomicAdd(p.stats + ((size_t)n0 * p.Co + wt * WT + col) * 2 + (idx & 1), t);
+        }
       }
     }
   }

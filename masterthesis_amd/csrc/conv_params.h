@@ -25,6 +25,8 @@ struct IgemmParams {
   const char* w;      // packed weights [CoRows][nchunks * 16 bytes]
   const float* bias;  // optional fp32 [nbias]
   char* y;            // output NHWC [N][Hout][Wout][Co]
+  float* stats;       // optional fp32 [N][Co][2]: += {sum, sum of squares} of the outputs per (image, channel)
+                      // (InstanceNorm statistics fused into the epilogue; needs Ho*Wo % 256 == 0, single phase)
   int N, Hi, Wi;
   int Cib;            // bytes per input pixel (padded channels * element size)
   unsigned x_bytes;   // size of the input tensor / weight pack in bytes (hardware range check of the

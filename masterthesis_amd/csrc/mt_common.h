@@ -114,4 +114,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane of the row gets the total.
+// quad_perm [1,0,3,2] (xor 1), [2,3,0,1] (xor 2), row_half_mirror, row_mirror: 4 VALU ops, no LDS traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+  return v;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -186,7 +186,7 @@ def kernel_timer_stop():
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
-        stride, pad, pad_mode, act, slope, transposed, out_pad = cfg
+        stride, pad, pad_mode, act, slope, transposed, out_pad, want_stats, bias_grad = cfg
         lib = L.load()
         dt = compute_dtype()
         x = canon(x)
@@ -206,11 +206,17 @@ class _Conv(torch.autograd.Function):
         y = new_act(N, Co, ho.value, wo.value, dt, x.device)
         pack = _get_pack(owner, weight, desc, L.PACK_FWD)
         b = None if bias is None else _f32c(bias.detach())
+        # normalisation statistics of the output are accumulated (atomics) in the GEMM epilogue
+        sums = torch.zeros((N, padc(Co), 2), dtype=torch.float32, device=x.device) if want_stats else None
         timed = _KTIMER["match"] is not None and _KTIMER["match"](desc)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()), "mt_conv_fwd")
+        if want_stats:
+            L.check(lib.mt_conv_fwd_stats(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(sums), _stream()),
+                    "mt_conv_fwd_stats")
+        else:
+            L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()), "mt_conv_fwd")
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -218,12 +224,15 @@ class _Conv(torch.autograd.Function):
         ctx.desc = desc
         ctx.owner = owner
         ctx.bias_owner = bias
-        ctx.has_bias = bias is not None
+        ctx.has_bias = bias is not None and bias_grad
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
+        if want_stats:
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dsums=None):
         lib = L.load()
         x, weight, y = ctx.saved_tensors
         desc = ctx.desc
@@ -267,15 +276,22 @@ class _Conv(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01):
-    """act(conv2d(pad(x)) + bias): nn.ReflectionPad2d/zero pad + nn.Conv2d (+ activation)."""
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01, stats=False, bias_grad=True):
+    """act(conv2d(pad(x)) + bias): nn.ReflectionPad2d/zero pad + nn.Conv2d (+ activation).
+
+    stats=True: also return the per-(image, channel) {sum, sum of squares} of the output, accumulated in the
+    GEMM epilogue, for the normalisation layer that follows (pass it as ``sums=``).
+    bias_grad=False: the bias is added but receives no gradient -- for a conv directly followed by an
+    affine-free InstanceNorm the bias gradient is identically zero (the reference computes round-off there)."""
     pm = L.PAD_REFLECT if (pad_mode == "reflect" and pad > 0) else L.PAD_ZERO
-    return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0))
+    return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0, bool(stats),
+                                         bool(bias_grad)))
 
 
 def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
     """nn.ConvTranspose2d (+ activation); weight layout [Cin, Cout, kh, kw]."""
-    return _Conv.apply(x, weight, bias, (stride, pad, L.PAD_ZERO, _act_code(act), float(slope), True, out_pad))
+    return _Conv.apply(x, weight, bias, (stride, pad, L.PAD_ZERO, _act_code(act), float(slope), True, out_pad, False,
+                                         True))
 
 
 class _Linear(torch.autograd.Function):
@@ -319,7 +335,7 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------------------
 class _Norm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gb, gamma, beta, res, cfg):
+    def forward(ctx, x, gb, gamma, beta, res, sums, cfg):
         mode, act, slope, eps = cfg
         lib = L.load()
         x = canon(x)
@@ -327,8 +343,11 @@ class _Norm(torch.autograd.Function):
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
-        sums = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
-        L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
+        if sums is None:
+            sums = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
+            L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
+        elif tuple(sums.shape) != (N, Cp, 2):
+            raise RuntimeError(f"norm: precomputed statistics have shape {tuple(sums.shape)}, expected {(N, Cp, 2)}")
         coef = torch.empty((4, N, Cp), dtype=torch.float32, device=dev)  # scale, shift, mean, rstd
         gbc = None if gb is None else _f32c(gb.detach())
         gm = None if gamma is None else _f32c(gamma.detach())
@@ -380,22 +399,22 @@ class _Norm(torch.autograd.Function):
             dgamma = dgamma.view(gshape)
             dbeta = dbeta.view(bshape)
         dres = dy if ctx.needs_input_grad[4] else None
-        return dx, dgb, dgamma, dbeta, dres, None
+        return dx, dgb, dgamma, dbeta, dres, None, None
 
 
-def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5):
-    """act(InstanceNorm2d(affine=False)(x)) (+ res)"""
-    return _Norm.apply(x, None, None, None, res, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps)))
+def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
+    """act(InstanceNorm2d(affine=False)(x)) (+ res); ``sums`` = statistics from conv2d(..., stats=True)"""
+    return _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps)))
 
 
-def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5):
+def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
     """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
-    return _Norm.apply(x, gb, None, None, res, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps)))
+    return _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps)))
 
 
 def layer_norm_act(x, gamma, beta, act=None, slope=0.01, eps=1e-5):
     """reference LayerNorm (per-sample over C,H,W; per-channel affine) + activation"""
-    return _Norm.apply(x, None, gamma, beta, None, (L.NORM_LAYER, _act_code(act), float(slope), float(eps)))
+    return _Norm.apply(x, None, gamma, beta, None, None, (L.NORM_LAYER, _act_code(act), float(slope), float(eps)))
 
 
 # --------------------------------------------------------------------------------------

@@ -61,13 +61,22 @@ class ConvBlock(nn.Module):
             mods.append(_Marker(self.act))
         self.block = nn.Sequential(*mods)
 
-    def forward(self, x, res=None):
+    def forward(self, x, res=None, want_stats=False):
+        """want_stats: return (conv output, its normalisation statistics) for an external norm layer (AdaIN)."""
         conv = self.block[self._ci]
+        if want_stats:
+            assert self.norm is None and self.act is None and res is None
+            return ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+                              pad_mode=self.pad_mode, stats=True)
+        if self.norm == "instance":
+            # statistics come out of the GEMM epilogue; the bias in front of an affine-free InstanceNorm has an
+            # identically zero gradient (SURVEY.md Appendix D-4), so none is computed
+            y, sums = ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+                                 pad_mode=self.pad_mode, stats=True, bias_grad=False)
+            return ops.instance_norm_act(y, act=self.act, res=res, sums=sums)
         fused_act = self.act if self.norm is None else None
         y = ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
                        act=fused_act)
-        if self.norm == "instance":
-            return ops.instance_norm_act(y, act=self.act, res=res)
         if self.norm == "layer":
             y = self.block[self._ni](y, act=self.act)
         return y if res is None else ops.add(y, res)
@@ -163,8 +172,10 @@ class AdaINResnetBlock(nn.Module):
         self.dropout = nn.Identity()
 
     def forward(self, x, z):
-        h = self.norm(self.conv1(x), z, act=self.act)
-        return self.norm(self.conv2(h), z, res=x)
+        y, sums = self.conv1(x, want_stats=True)
+        h = self.norm(y, z, act=self.act, sums=sums)
+        y, sums = self.conv2(h, want_stats=True)
+        return self.norm(y, z, res=x, sums=sums)
 
 
 def _expand_planes(v, ref):

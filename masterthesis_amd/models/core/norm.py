@@ -33,6 +33,6 @@ class AdaptiveInstanceNorm(nn.Module):
         self.num_features = num_features
         self.fc = nn.Linear(style_dim, num_features * 2)
 
-    def forward(self, x, s, act=None, res=None):
+    def forward(self, x, s, act=None, res=None, sums=None):
         h = ops.linear(s, self.fc.weight, self.fc.bias)
-        return ops.adain_act(x, h, act=act, res=res)
+        return ops.adain_act(x, h, act=act, res=res, sums=sums)

@@ -69,7 +69,7 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     # Phase-4 gradients at initialisation are cancellation dominated (tiny-width fixtures: even the
     # reference's fp32 CPU run is 3-8 % away from fp64 there), so bf16 storage only gets a sanity bound.
     if precision == "fp32":
-        grad_tol = [5e-3] * 5 + [2e-2, 2e-2]      # phase 4: cancellation dominated, see above
+        grad_tol = [5e-3] * 5 + [1e-1, 1e-1]      # phase 4: cancellation dominated (the reference itself: 3-8 %)
     else:
         # bf16 storage: op-level parity is pinned in test_ops_gpu.py.  At step level the L1 losses make the
         # gradient discontinuous in the forward activations: bf16 forward noise (~1 %) flips sign(img - fake)
