@@ -14,13 +14,13 @@
 
 // block = cchunks channel-chunks x npl pixel lanes.  grid = (pixel blocks, N)
 template <bool BF16, bool BWD>
-__global__ __launch_bounds__(256) void nc_stats_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
+__global__ __launch_bounds__(1024) void nc_stats_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ sums,
                                                        int HW, int cchunks, int pix_per_block, int act,
                                                        float slope) {
   constexpr int V = Elem<BF16>::V;
-  __shared__ float red[256 * 2];
+  __shared__ float red[1024 * 2];
   const int n = blockIdx.y;
   const int cq = threadIdx.x % cchunks;
   const int pl = threadIdx.x / cchunks;
@@ -85,14 +85,16 @@ static int launch_stats(int dtype, const void* x, const void* dy, const float* s
     mt_set_error("nc_stats: memset failed");
     return 2;
   }
-  const int npl = 256 / cchunks;
-  int ppb = npl * 32;  // 32 pixels per thread
+  // 1024-thread blocks (16 waves per CU in flight for the HBM stream), 8 pixels per thread
+  const int NT = 1024;
+  const int npl = NT / cchunks;
+  int ppb = npl * 8;
   if (ppb < 64) ppb = 64;
   dim3 grid(cdiv(HW, ppb), N);
   if (dtype == MT_BF16)
-    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(NT), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
   else
-    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(NT), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
   MT_LAUNCH_CHECK();
   return 0;
 }
