@@ -36,7 +36,10 @@ class GradReducer:
     the current stream wait for that buffer only.  Works with any backend (gloo on CPU for tests)."""
 
     def __init__(self, group=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # MT_FORCE_REDUCER=1 keeps the exchange path active at world_size 1 (exercises RCCL + the side stream
+        # on a single GPU; the all-reduce is then an identity)
+        force = os.environ.get("MT_FORCE_REDUCER", "0") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.group = group
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.side = None

@@ -53,3 +53,44 @@ def test_inference_surface(precision, tmp_path, hip_device):
         assert o.shape == (2, 3, 54 // 4 * 4 + (4 if 54 % 4 else 0) if False else o.shape[2], o.shape[3])
         assert o.shape[0] == 2 and o.shape[1] == 3 and torch.isfinite(o).all() and o.abs().max() <= 1.0
     assert secs >= 0 and gib >= 0
+
+
+def test_rccl_exchange_path_single_rank(tmp_path, hip_device, monkeypatch):
+    """World-size-1 RCCL process group with the gradient exchange forced on: the side-stream all-reduce,
+    event waits and per-network Adam ordering run for real; losses must equal a run without the exchange."""
+    import socket
+    import torch.distributed as dist
+    from helpers import load_gold, product_args, sub
+    from masterthesis_amd import models
+    from masterthesis_amd.models.core import misc
+
+    def run(force):
+        monkeypatch.setenv("MT_FORCE_REDUCER", "1" if force else "0")
+        z, meta = load_gold("adain_step_d2")
+        M = models.AdaINModel(product_args(meta["args"], str(tmp_path), "fp32"))
+        assert M.reducer.enabled == force
+        M.initialize()
+        for net in M.model:
+            M.model[net].load_state_dict(sub(z, f"init/{net}"))
+        out = []
+        for it in range(2):
+            misc.set_random_source(misc.ReplaySource([z[f"rng/{it}/{i}"] for i in range(meta["rng_counts"][it])]))
+            M.update_lr()
+            M.set_inputs(sub(z, "batch"))
+            M.optimize_parameters(it)
+            out.append(dict(M.sync_losses()))
+        misc.set_random_source(None)
+        return out
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        a, b = run(True), run(False)
+    finally:
+        dist.destroy_process_group()
+    for la, lb in zip(a, b):
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
