@@ -80,7 +80,8 @@ extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, vo
   long s_ci, s_co;  // element strides of ci / co in the reference layout
   if (d->transposed) { s_ci = (long)d->Co * K2; s_co = K2; }   // [Ci][Co][kh][kw]
   else { s_co = (long)d->Ci * K2; s_ci = K2; }                 // [Co][Ci][kh][kw]
-  const bool rows_are_co = d->transposed ? (which == MT_PACK_FWD) : (which == MT_PACK_FWD);
+  // thin 1x1 convolutions (pointwise_kernels.hip) use the [co][ci] image for forward AND data gradient
+  const bool rows_are_co = mt_pointwise_small(d) || (which == MT_PACK_FWD);
   if (rows_are_co) { p.R = d->Co; p.C = d->Ci; p.sr = s_co; p.sc = s_ci; }
   else { p.R = d->Ci; p.C = d->Co; p.sr = s_ci; p.sc = s_co; }
   p.Rp = mt_padc(p.R);
@@ -175,6 +176,7 @@ extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pac
   int Ho, Wo;
   mt_conv_out_hw(d, &Ho, &Wo);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  if (mt_pointwise_small(d)) return mt_pw_fwd(d, x, pack_fwd, bias, y, (long)d->N * d->H * d->W, s);
   if (!d->transposed)
     return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s);
   return scatter_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad, d->act, s);
@@ -215,6 +217,7 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   int Ho, Wo;
   mt_conv_out_hw(d, &Ho, &Wo);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  if (mt_pointwise_small(d)) return mt_pw_bwd_data(d, dy, pack_bwd, dx, (long)d->N * d->H * d->W, s);
   if (d->transposed)
     return gather_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, MT_PAD_ZERO, MT_ACT_NONE, s);
   const int P = (d->pad_mode == MT_PAD_REFLECT) ? d->pad : 0;
@@ -262,6 +265,22 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   mt_conv_out_hw(d, &Ho, &Wo);
   const int sz = esz(d->dtype), V = vec(d->dtype);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  if (mt_pointwise_small(d)) {
+    // streaming outer-product reduction into fp32 [Cop][Cip], then the generic unpack (rows = co)
+    if (dw != nullptr) {
+      if (hipMemsetAsync(ws, 0, (size_t)Cop * Cip * sizeof(float), s) != hipSuccess) { mt_set_error("memset"); return 2; }
+      if (mt_pw_bwd_weight(d, x, dy, (float*)ws, (long)d->N * d->H * d->W, s)) return 2;
+      PackParams u;
+      memset(&u, 0, sizeof(u));
+      u.kW = 1; u.ntaps = 1; u.R = d->Co; u.C = d->Ci; u.Cp = Cip;
+      if (d->transposed) { u.sr = 1; u.sc = d->Co; } else { u.sr = d->Ci; u.sc = 1; }
+      if (mt_launch_unpack((const float*)ws, dw, u, 1, (long)Cop * Cip, accumulate, s)) return 2;
+    }
+    if (dbias != nullptr) {
+      if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, Cop, d->Co, accumulate, s)) return 2;
+    }
+    return 0;
+  }
   WgradParams p;
   memset(&p, 0, sizeof(p));
   PackParams u;

@@ -83,3 +83,10 @@ int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nspli
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, hipStream_t s);
+
+// thin 1x1 convolutions (pointwise_kernels.hip); the launchers return -1 if no instantiation matches
+struct mt_conv_desc;
+bool mt_pointwise_small(const mt_conv_desc* d);
+int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const float* bias, void* y, long npix, hipStream_t s);
+int mt_pw_bwd_data(const mt_conv_desc* d, const void* dy, const void* wpack, void* dx, long npix, hipStream_t s);
+int mt_pw_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* out, long npix, hipStream_t s);

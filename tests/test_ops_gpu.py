@@ -55,6 +55,7 @@ CONV_CASES = [
     ("k1_pad1_patch", 2, 16, 4, 4, 1, 1, 1, 1, "zero", False, None),
     ("k4_valid_cls", 2, 16, 4, 4, 2, 4, 1, 0, "zero", False, None),
     ("k1_shortcut", 2, 8, 8, 8, 16, 1, 1, 0, "zero", True, None),
+    ("k1_thin_head", 2, 128, 6, 6, 4, 1, 1, 0, "zero", True, None),
     ("k7s2_reflect_dc", 1, 8, 20, 20, 8, 7, 2, 1, "reflect", True, None),
     ("k3s1_wide", 2, 64, 20, 20, 160, 3, 1, 1, "reflect", False, "relu"),
     ("k3s1_256", 1, 256, 16, 16, 256, 3, 1, 1, "reflect", False, None),
@@ -113,6 +114,8 @@ CONVT_CASES = [
     ("k1s1_tanh_rgb", 2, 8, 12, 12, 3, 1, 1, 0, 0, False, "tanh"),
     ("k3s2_wide", 1, 128, 10, 10, 64, 3, 2, 1, 1, True, None),
     ("k4s2p1", 1, 8, 6, 6, 8, 4, 2, 1, 0, False, None),
+    ("k1s1_tanh_rgb64", 2, 64, 24, 24, 3, 1, 1, 0, 0, False, "tanh"),     # the decoder's to-RGB layer
+    ("k1s1_bias_16", 1, 16, 9, 7, 5, 1, 1, 0, 0, True, None),
 ]
 
 
