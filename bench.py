@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--ms_dis", action="store_true", help="multi-scale discriminators (default: single-scale, "
                     "the reference's default)")
-    ap.add_argument("--cpu_res", type=int, default=64, help="resolution of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu_res", type=int, default=128, help="resolution of the bounded CPU-baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     o = ap.parse_args()
 
@@ -165,6 +165,14 @@ def main():
     tot_flop = sum(2.0 * n * (o.crop_size // 4) ** 2 * 256 * 2304 for _, n in k1_ms)
     tot_ms = sum(t for t, _ in k1_ms)
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if k1_ms else 0.0
+    # HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE x2 correction +
+    # WRITE_SIZE, MI355X_MICROARCH.md) collected with tools/bench_k1.py on this exact shape; see profiles/
+    traffic, mfma_busy = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "round1_k1_fwd_pmc.json")
+    if os.path.exists(pmc_path) and o.precision == "bf16" and o.batch_size == 8 and o.crop_size == 256:
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic, mfma_busy = pmc.get("traffic_bytes_per_launch"), pmc.get("mfma_busy_fraction")
     out = {
         "metric": "train images/sec (G+D step), AdaINModel 256x256", "value": round(value, 3), "unit": "images/sec",
         "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -177,10 +185,12 @@ def main():
                    "step_tflop_algorithmic": round(f_step, 2),
                    "step_tflops_achieved_per_gpu": round(f_step / (ms_per_step * 1e-3), 1),
                    "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4)},
-        "roofline": {"bound": "mfma", "kernel": "igemm_kernel<bf16,128> fwd 3x3 s1 256->256 @64x64" if o.precision == "bf16"
-                     else "igemm_kernel<f32,128> fwd 3x3 s1 256->256 @64x64",
+        "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<bf16,256,256,512>" if o.precision == "bf16" else
+                                                 "igemm_kernel<f32,256,256,512>") + " fwd 3x3 s1 256->256 @64x64 "
+                                                "(+ fused InstanceNorm-statistics epilogue)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "mfma_busy_fraction_pmc": mfma_busy,
                      "launches_timed": len(k1_ms), "avg_launch_ms_full_batch": round(k1_avg_ms, 4),
                      "flop_per_launch_full_batch": k1_flop},
         "final_losses": {k: round(float(v), 5) for k, v in losses.items()},
