@@ -17,26 +17,7 @@
 // tile the B operand, so each lane ends up with 4 consecutive output channels of one pixel
 // (a packed 8/16-byte NHWC store).
 // ------------------------------------------------------------------------------------------
-template <bool BF16>
-__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x4& b) {
-  if constexpr (BF16) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-  } else {
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]),
-                                                 acc, 0, 0, 0);
-  }
-}
-
-// bijective XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
-// contiguous range of tiles so neighbouring pixel tiles (shared halo rows) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int b, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (b >> 3);
-}
+#include "conv_device.h"
 
 // Tile geometries (WT output channels x PT pixels per block, NT threads):
 //   <128,128,256>, <64,128,256>, <32,128,256>, <16,128,256>: 4 waves, wave tile up to 64x64, 2 blocks/CU
@@ -339,6 +320,9 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 }
 
 template <bool BF16>
+int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s);   // conv_pipe_kernel.hip
+
+template <bool BF16>
 static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
   int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
@@ -353,8 +337,9 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
     total += p.ph[i].nblk;
   }
   if (total == 0) return 0;
-  if (WT == 256) hipLaunchKernelGGL((igemm_kernel<BF16, 256, 256, 512>), dim3(total), dim3(512), 0, s, p);
-  else if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
+  // 256x256 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
+  if (WT == 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 32) hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((igemm_kernel<BF16, 16, 128, 256>), dim3(total), dim3(256), 0, s, p);

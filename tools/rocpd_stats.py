@@ -8,14 +8,18 @@ import sys
 
 def main():
     db, top = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    by_grid = len(sys.argv) > 3 and sys.argv[3] == "grid"   # split every kernel by its grid size
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    rows = c.execute(f"select s.kernel_name, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id").fetchall()
+    rows = c.execute(f"select s.kernel_name, d.end - d.start, d.grid_size_x, d.workgroup_size_x from {kd} d "
+                     f"join {ks} s on d.kernel_id = s.id").fetchall()
     agg = {}
-    for name, dur in rows:
+    for name, dur, gx, wx in rows:
         name = re.sub(r"\(.*", "", name)
+        if by_grid:
+            name = f"{name[:48]} g{gx // max(wx, 1)}"
         a = agg.setdefault(name, [0, 0, 1 << 62, 0])
         a[0] += 1
         a[1] += dur

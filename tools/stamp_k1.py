@@ -1,0 +1,25 @@
+"""In-kernel s_memtime stamps of the 256x256 gather-GEMM (diagnostic build: make -C masterthesis_amd/csrc STAMPS=1)."""
+import sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np, torch
+from masterthesis_amd import hip_ops as ops, _lib
+dev = torch.device('cuda:0')
+ops.set_compute_dtype(torch.bfloat16)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+x = ops.canon(torch.randn(N, 256, 64, 64, device=dev))
+w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
+with torch.no_grad():
+    for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
+torch.cuda.synchronize()
+lib = C.CDLL(_lib.LIB_PATH)
+buf = np.zeros(8 * 4096, dtype=np.uint64)
+lib.mt_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
+rc = lib.mt_debug_stamps(buf.ctypes.data, buf.nbytes)
+nb = N * 64 * 64 // 256
+s = buf.reshape(4096, 8)[:nb, :4].astype(np.int64)
+d = np.diff(s, axis=1)
+print("rc", rc, "blocks", nb)
+print("median cycles: prologue %d  mainloop %d  epilogue %d  total %d" % tuple(list(np.median(d, axis=0)) + [np.median(s[:, 3] - s[:, 0])]))
+print("p90    cycles: prologue %d  mainloop %d  epilogue %d" % tuple(np.percentile(d, 90, axis=0)))
+print("span first start -> last end: %d cycles" % (s[:, 3].max() - s[:, 0].min()))
+print("start spread: %d  end spread: %d" % (s[:, 0].max() - s[:, 0].min(), s[:, 3].max() - s[:, 3].min()))
