@@ -326,7 +326,10 @@ template <bool BF16>
 static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
   int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
-  if (p.nphase == 1 && p.CoRows % 256 == 0) {
+  // (the ping-pong kernel steps whole 4-chunk k-steps inside a tap and marks zero lanes with offsets >= 2 GiB)
+  const bool pipe_ok = p.cpc % 4 == 0 && p.ph[0].ntaps <= 25 /* MT_PIPE_MAX_TAPS */ && p.x_bytes < 0x7f000000u &&
+                       (double)p.CoRows * p.ph[0].ntaps * p.cpc * 16.0 < (double)0x7f000000u;
+  if (p.nphase == 1 && p.CoRows % 256 == 0 && pipe_ok) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
     if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
   }

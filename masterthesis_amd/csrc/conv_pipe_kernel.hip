@@ -1,23 +1,29 @@
-// Software-pipelined gather-GEMM (same math and parameter block as igemm_kernel in conv_kernels.hip).
+// Ping-pong software-pipelined gather-GEMM for 256x256 tiles (same math and parameter block as igemm_kernel
+// in conv_kernels.hip; chosen by launch_igemm_t there).  gfx950 only.
 //
-// 32-deep k-steps (64-byte tile rows), an NS-stage LDS ring filled by LDS-DMA
-// (buffer_load_dwordx4 ... lds) that runs NS-1 stages ahead, ONE raw s_barrier per k-step and a COUNTED
-// s_waitcnt vmcnt((NS-2)*PPS): the copies of the newest NS-2 stages stay in flight across the barrier
-// (a __syncthreads() would drain them with vmcnt(0) -- with the 2-stage kernel 51 % of the wave cycles
-// sit in that wait).  Every wave issues exactly PPS copies per stage (out-of-range offsets -> zeros, also
-// past the end of K), so the count is a compile-time constant in the steady state and in the tail.
-//
-//   iteration ks:  s_waitcnt vmcnt((NS-2)*PPS)  -> this wave's copies of stage ks have landed
-//                  s_barrier                    -> everybody's have; everybody finished reading ks-1
-//                  ds_read fragments of stage ks; MFMAs, interleaved with the copies of stage ks+NS-1
-//                  (which overwrite the ring slot of stage ks-1)
+//  * 32-deep k-steps (64-byte tile rows) in an NS-stage LDS ring filled by LDS-DMA
+//    (buffer_load_dwordx4 ... lds) running NS-1 stages ahead; the wait is a COUNTED
+//    s_waitcnt vmcnt((NS-2)*PPS), so the copies of the newest stages stay in flight across the barriers
+//    (the 2-stage kernel drains with vmcnt(0) in __syncthreads(): 51 % of its wave cycles sit there).
+//    Every wave issues exactly PPS copies per stage (offsets >= 2 GiB -> zeros, also past the end of K), so
+//    the count is a compile-time constant in the steady state and in the tail.
+//  * 8 waves = two groups of four (one wave of each group per SIMD) that alternate, half a k-step apart,
+//    between a memory phase (copies + fragment reads) and a compute phase (32 back-to-back MFMAs).
+//  * all gather addressing (filter tap offsets, reflection / zero padding) is resolved once per tile into an
+//    LDS table; the main loop has no branch and no address arithmetic beyond table entry + chunk offset
+//    (a branchy per-tap recomputation in the loop cost 17 % of the main-loop cycles).
+//  * 16-byte epilogue stores: weight rows are staged in a permuted order so that a lane ends up with 8
+//    consecutive output channels of a pixel.
+// In-kernel s_memtime stamps (diagnostic build, tools/diag_build.sh + tools/stamp_k1.py) on 3x3 256->256,
+// 16x64x64: prologue 7.7k, main loop 91k (1266 cycles per k-step against 1024 of pure MFMA issue), epilogue
+// 20k cycles (all 256 CUs store 128 KiB at once: HBM-write bound).
 #include "conv_device.h"
 #include <type_traits>
 
 #ifdef MT_STAMPS
 // diagnostic build only (make STAMPS=1): s_memtime stamps of wave 0 of every block -> tools/stamp_k1.py
-__device__ unsigned long long mt_stamp_buf[8 * 4096];
-#define MT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mt_stamp_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long mt_stamp_buf[16 * 4096];
+#define MT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mt_stamp_buf[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int mt_debug_stamps(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mt_stamp_buf), bytes < sizeof(mt_stamp_buf) ? bytes : sizeof(mt_stamp_buf));
 }
@@ -30,27 +36,31 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+constexpr int MT_PIPE_MAX_TAPS = 25;   // rows of the per-tile gather-offset table (+1 all-zero row)
+
 template <bool BF16, int WT, int PT, int NT, int NS>
 __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   constexpr int NW = NT / 64;
-  constexpr int WC = (WT == 256) ? 128 : ((WT >= 64) ? 64 : WT);   // wave tile: output channels
-  constexpr int WP = (WT >= 128) ? 64 : 32;                        // wave tile: pixels
+  constexpr int WC = 128, WP = 64;                  // wave tile: 128 output channels x 64 pixels
   constexpr int NWP = PT / WP;
   constexpr int FC = WC / 16, FP = WP / 16;
   constexpr int SZ = BF16 ? 2 : 4;
   constexpr int NXL = PT / 16 / NW;                 // pixel-tile copies per wave per stage
-  constexpr int NWL = ((WT + 15) / 16 + NW - 1) / NW;   // weight-tile copies per wave per stage (incl. dummies)
-  constexpr int WR = NWL * NW * 16;                 // weight rows allocated per stage (>= WT)
+  constexpr int NWL = WT / 16 / NW;                 // weight-tile copies per wave per stage
+  constexpr int WR = WT;                            // weight rows per stage
   constexpr int PPS = NXL + NWL;                    // copies per wave per stage
   constexpr int STAGE = (WR + PT) * 4;              // u32x4 per stage (4 chunks per 64-byte row)
-  static_assert((NT / 64) == (PT / WP) * (WT / WC), "wave grid must cover the block tile");
-  static_assert(NXL * NW * 16 == PT, "pixel tile must be a whole number of copy instructions per wave");
+  constexpr int TROWS = MT_PIPE_MAX_TAPS + 1;
+  static_assert(NW == 8 && NW == (PT / WP) * (WT / WC), "two wave groups of four, one wave of each per SIMD");
+  static_assert(NXL * NW * 16 == PT && NWL * NW * 16 == WT, "tiles are a whole number of copies per wave");
   static_assert(NS >= 3 && (NS - 2) * PPS <= 63, "vmcnt range");
   static_assert(FC % 2 == 0, "the epilogue stores fragment pairs");
+  static_assert((NS * STAGE * 16 + TROWS * PT * 4) <= 160 * 1024, "LDS budget");
 
-  // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt)
-  __shared__ u32x4 smem[NS * STAGE + 16];
-  int* sTap = reinterpret_cast<int*>(&smem[NS * STAGE]);
+  // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt):
+  // NS stages of (weight tile | pixel tile), then the gather-offset table T[tap][pixel of the tile]
+  __shared__ u32x4 smem[NS * STAGE + TROWS * PT / 4];
+  unsigned* const sT = reinterpret_cast<unsigned*>(&smem[NS * STAGE]);
 
   MT_STAMP(0);
   const int tid = threadIdx.x;
@@ -68,66 +78,30 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   const int ph_nchunks = ph_ntaps * p.cpc;
   const char* const ph_w = p.w + ph.w_off;
   wg -= ph.blk0;
-  if (tid < 64) {
-    const int t = ph.tap0 + tid;
-    sTap[tid] = tid < ph_ntaps ? (((int)p.dh[t] << 16) | ((int)p.dw[t] & 0xffff)) : 0;
-  }
   const int wt = wg % nWT, pt = wg / nWT;
-
-  // ---- staging coordinates: a copy instruction writes 64 lanes x 16 B = 16 tile rows lane-linearly; the
-  // bank swizzle (chunk ^ ((row >> 1) & 3), conflict-free for the ds_read_b128 fragment reads of 64-byte
-  // rows) is applied to the SOURCE chunk
-  const int rsub = lane >> 2;
-  const int c = (lane & 3) ^ ((rsub >> 1) & 3);
   const int HoWo = ph_Ho * ph_Wo;
-  int hb[NXL], wb[NXL];
-  unsigned ib[NXL];
-  unsigned rvm = 0;
-#pragma unroll
-  for (int i = 0; i < NXL; i++) {
-    const int m = pt * PT + 16 * (wvu + NW * i) + rsub;
+
+  // ---- gather-offset table: T[t][r] = byte offset of the input pixel that filter tap t reads for tile
+  // pixel r (reflection / zero padding resolved here, ONCE per tile), or OOB where the operand is zero: the
+  // buffer load range-checks and returns 0 for offsets >= 2 GiB (the host checks the tensors are smaller).
+  // Row ntaps is all-OOB (the pipeline runs NS-1 stages past the end of K).  The main loop is then free of
+  // address arithmetic beyond "table entry + chunk offset" and of any branch.
+  constexpr unsigned OOB = 0x80000000u;
+  {
+    const int r = tid & (PT - 1);
+    const int m = pt * PT + r;
     const bool rv = m < ph_M;
-    rvm |= (rv ? 1u : 0u) << i;
     const int mm = rv ? m : 0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
     const int ho = rem / ph_Wo;
     const int wo = rem - ho * ph_Wo;
-    hb[i] = ho * p.is;
-    wb[i] = wo * p.is;
-    ib[i] = (unsigned)n * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
-  }
-  int q = c;
-  int tap = q / p.cpc;
-  int cq = q - tap * p.cpc;
-  const int step_t = 4 / p.cpc, step_r = 4 % p.cpc;
-
-  unsigned wo32[NWL];
-  unsigned wokm = 0;
-#pragma unroll
-  for (int i = 0; i < NWL; i++) {
-    const int rs = 16 * (wvu + NW * i) + rsub;           // LDS row of the weight tile (fragment order)
-    // channel held by that row: within each 32-row fragment pair, row (a&1)*16 + r <- channel (r>>2)*8 + (a&1)*4 + (r&3)
-    const int rl = (rs & ~31) | ((((rs & 15) >> 2) << 3) | (((rs >> 4) & 1) << 2) | (rs & 3));
-    const int row = wt * WT + rl;
-    const bool ok = (rs < WT) && (row < p.CoRows);
-    wokm |= (ok ? 1u : 0u) << i;
-    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)ph_nchunks + (unsigned)c) * 16u;
-  }
-  unsigned xo32[2];
-  static_assert(NXL <= 2, "xo32 is literal-sized (hipcc drops the host stub for a dependent-size lambda capture)");
-  unsigned xokm = 0;
-  auto retap = [&]() {
-    xokm = 0;
-#pragma unroll
-    for (int i = 0; i < NXL; i++) xo32[i] = 0xfffffff0u;
-    if (tap < ph_ntaps) {
-      const int t = sTap[tap];
-      const int dh = t >> 16, dw = (int)(short)(t & 0xffff);
-#pragma unroll
-      for (int i = 0; i < NXL; i++) {
-        int hi = hb[i] + dh, wi = wb[i] + dw;
-        bool ok = (rvm >> i) & 1u;
+    const unsigned ibase = (unsigned)n * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
+    for (int t = tid / PT; t <= ph_ntaps; t += NT / PT) {
+      unsigned off = OOB;
+      if (t < ph_ntaps) {
+        int hi = ho * p.is + p.dh[ph.tap0 + t], wi = wo * p.is + p.dw[ph.tap0 + t];
+        bool ok = rv;
         if (p.pad_mode == MT_PAD_REFLECT) {
           hi = hi < 0 ? -hi : hi;
           hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
@@ -135,14 +109,33 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
           wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
         } else {
           ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-          hi = ok ? hi : 0;
-          wi = ok ? wi : 0;
         }
-        xo32[i] = ok ? ib[i] + (unsigned)(hi * p.Wi + wi) * (unsigned)p.Cib + (unsigned)cq * 16u : 0xfffffff0u;
-        xokm |= (ok ? 1u : 0u) << i;
+        if (ok) off = ibase + (unsigned)(hi * p.Wi + wi) * (unsigned)p.Cib;
       }
+      sT[t * PT + r] = off;
     }
-  };
+  }
+
+  // ---- staging coordinates: a copy instruction writes 64 lanes x 16 B = 16 tile rows lane-linearly; the
+  // bank swizzle (chunk ^ ((row >> 1) & 3), conflict-free for the ds_read_b128 fragment reads of 64-byte
+  // rows) is applied to the SOURCE chunk.  The host guarantees cpc % 4 == 0, so a k-step (4 chunks) never
+  // straddles a filter tap and the tap index is wave-uniform.
+  const int rsub = lane >> 2;
+  const int c = (lane & 3) ^ ((rsub >> 1) & 3);
+  unsigned wo32[2], xo32[2];
+  int prow[2];                  // this lane's pixel rows of the tile (one per copy instruction)
+  static_assert(NWL <= 2 && NXL <= 2, "literal-sized arrays (hipcc drops the host stub for a dependent-size lambda capture)");
+#pragma unroll
+  for (int i = 0; i < NXL; i++) prow[i] = 16 * (wvu + NW * i) + rsub;
+#pragma unroll
+  for (int i = 0; i < NWL; i++) {
+    const int rs = 16 * (wvu + NW * i) + rsub;           // LDS row of the weight tile (fragment order)
+    // channel held by that row: within each 32-row fragment pair, row (a&1)*16 + r <- channel (r>>2)*8 + (a&1)*4 + (r&3)
+    const int rl = (rs & ~31) | ((((rs & 15) >> 2) << 3) | (((rs >> 4) & 1) << 2) | (rs & 3));
+    const int row = wt * WT + rl;
+    wo32[i] = row < p.CoRows ? ((unsigned)row * (unsigned)ph_nchunks + (unsigned)c) * 16u : OOB;
+  }
+  int tap_s = 0, cqb = 0;       // wave-uniform: filter tap and first chunk inside it of the NEXT stage to issue
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw =
@@ -150,32 +143,35 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   char* const lds0 = reinterpret_cast<char*>(&smem[0]);
 
-  // one copy instruction of the stage being filled into ring slot `slot` (j in [0, PPS))
-  auto issue_piece = [&](int slot, int j) {
+  // the PPS copy instructions of one stage into ring slot `slot`
+  // (no K-tail check on the weight side: there the pixel operand is zero, and reading into the next pack row
+  // or past the end -- range-checked -> 0 -- only multiplies finite weights by 0)
+  auto issue_stage = [&](int slot) {
     char* base = lds0 + slot * (STAGE * 16);
-    if (j < NWL) {
-      const int i = j;
-      const unsigned o = ((wokm >> i) & 1u) ? wo32[i] : 0xfffffff0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * i) * 1024), 16, o, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NWL; i++) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * i) * 1024), 16, wo32[i], 0, 0, 0);
       wo32[i] += 64u;
-    } else {
-      const int i = j - NWL;
+    }
+#pragma unroll
+    for (int i = 0; i < NXL; i++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(base + WR * 64 + (wvu + NW * i) * 1024), 16, xo32[i], 0, 0,
                                                0);
-    }
   };
-  auto issue_end = [&]() {   // advance the gather state by one k-step (4 chunks)
-    q += 4;
-    const int otap = tap;
-    tap += step_t;
-    cq += step_r;
-    if (cq >= p.cpc) { cq -= p.cpc; tap++; }
-    if (tap != otap) {
-      retap();
-    } else {
+  // table entries of the stage after the one just issued (scalar tap / chunk bookkeeping, two LDS reads)
+  unsigned tq[2];
+  auto next_lookup = [&]() {
+    cqb += 4;
+    const bool wrap = cqb >= p.cpc;
+    cqb = wrap ? 0 : cqb;
+    tap_s = wrap ? tap_s + 1 : tap_s;
+    tap_s = tap_s > ph_ntaps ? ph_ntaps : tap_s;
 #pragma unroll
-      for (int i = 0; i < NXL; i++) xo32[i] += ((xokm >> i) & 1u) ? 64u : 0u;
-    }
+    for (int i = 0; i < NXL; i++) tq[i] = sT[tap_s * PT + prow[i]];
+  };
+  auto next_offsets = [&]() {
+#pragma unroll
+    for (int i = 0; i < NXL; i++) xo32[i] = tq[i] + (unsigned)((cqb + c) * 16);
   };
 
   f32x4 acc[FC][FP];
@@ -184,103 +180,80 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (ph_nchunks + 3) >> 2;
-  __syncthreads();  // tap table visible
-  retap();
+  const int nk = ph_nchunks >> 2;
+  __syncthreads();  // offset table visible
+#pragma unroll
+  for (int i = 0; i < NXL; i++) xo32[i] = sT[prow[i]] + (unsigned)(c * 16);
   // prologue: stages 0 .. NS-2
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) {
-#pragma unroll
-    for (int j = 0; j < PPS; j++) issue_piece(s, j);
-    issue_end();
+    issue_stage(s);
+    next_lookup();
+    next_offsets();
   }
-  if constexpr (NW == 8) wait_vmcnt<(NS - 2) * PPS>();
+  wait_vmcnt<(NS - 2) * PPS>();
   MT_STAMP(1);
 
-  auto read_frags = [&](int slot_, u32x4* wf, u32x4* xf) {
-    const u32x4* sWs = &smem[slot_ * STAGE];
-    const u32x4* sXs = sWs + WR * 4;
-#pragma unroll
-    for (int a = 0; a < FC; a++) {
-      const int row = wcI * WC + a * 16 + fr;
-      wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
-    }
-#pragma unroll
-    for (int b = 0; b < FP; b++) {
-      const int row = wpI * WP + b * 16 + fr;
-      xf[b] = sXs[row * 4 + (fg ^ ((row >> 1) & 3))];
-    }
-  };
+  // ---- ping-pong main loop: waves 0-3 and 4-7 (one of each per SIMD) alternate between a MEMORY phase
+  // (LDS-DMA of stage ks+NS-1, fragment reads of stage ks) and a COMPUTE phase (32 back-to-back MFMAs), half
+  // a k-step apart, so each SIMD's matrix pipe always has one wave feeding it while the other one waits on
+  // the texture path / LDS.  Every wave executes the same number of s_barriers (2*nk + 2).
+  //   slot reuse: stage ks+NS-1 overwrites the slot of stage ks-1, whose last readers (the partner group's
+  //               memory phase ks-1) finished before the barrier this phase started from;
+  //   landing:    at the end of memory phase ks a wave waits until all but its newest (NS-2)*PPS copies are
+  //               done, i.e. its part of stage ks+1 is in LDS before the barrier in front of anyone's reads.
+  const int grp = wvu >> 2;
   int slot = 0;   // ring slot of stage ks
-  if constexpr (NW == 8) {
-    // ---- ping-pong: waves 0-3 and 4-7 (one of each per SIMD) alternate between a MEMORY phase (fragment
-    // reads of stage ks, LDS-DMA of stage ks+NS-1) and a COMPUTE phase (32 back-to-back MFMAs), half a k-step
-    // apart, so each SIMD's matrix pipe always has one wave feeding it while the other waits on LDS / the
-    // texture path.  Every wave executes the same number of s_barriers (2*nk + 1).
-    const int grp = wvu >> 2;
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // every wave's prologue copies of stage 0 have landed
-    asm volatile("" ::: "memory");
-    if (grp) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int ks = 0; ks < nk; ks++) {
-      int fill = slot - 1;
-      fill = fill < 0 ? NS - 1 : fill;
-      u32x4 wf[FC], xf[FP];
-      read_frags(slot, wf, xf);
-#pragma unroll
-      for (int j = 0; j < PPS; j++) issue_piece(fill, j);
-      issue_end();
-      // this wave's copies of stage ks+1 have landed; its fragments are in registers
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PPS) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < FC; a++)
-#pragma unroll
-        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-    if (!grp) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    for (int ks = 0; ks < nk; ks++) {
-      wait_vmcnt<(NS - 2) * PPS>();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      int fill = slot - 1;                 // slot of stage ks-1 == slot of stage ks+NS-1
-      fill = fill < 0 ? NS - 1 : fill;
-      u32x4 wf[FC], xf[FP];
-      read_frags(slot, wf, xf);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave's copies of stage 0 have landed
+  asm volatile("" ::: "memory");
+  if (grp) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int ks = 0; ks < nk; ks++) {
+    int fill = slot - 1;
+    fill = fill < 0 ? NS - 1 : fill;
+    u32x4 wf[FC], xf[FP];
+    // copies first: the texture path works on them while the LDS serves the fragment reads
+    issue_stage(fill);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const u32x4* sWs = &smem[slot * STAGE];
+      const u32x4* sXs = sWs + WR * 4;
 #pragma unroll
       for (int a = 0; a < FC; a++) {
-        // the PPS copies of stage ks+NS-1 are spread over the first MFMA groups
-        if (FC >= PPS) { if (a < PPS) issue_piece(fill, a); }
-        else {
-#pragma unroll
-          for (int j = (a * PPS) / FC; j < ((a + 1) * PPS) / FC; j++) issue_piece(fill, j);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
-        __builtin_amdgcn_s_setprio(0);
+        const int row = wcI * WC + a * 16 + fr;
+        wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
       }
-      issue_end();
-      slot = slot + 1 == NS ? 0 : slot + 1;
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        const int row = wpI * WP + b * 16 + fr;
+        xf[b] = sXs[row * 4 + (fg ^ ((row >> 1) & 3))];
+      }
     }
+    next_lookup();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PPS) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < FC; a++)
+#pragma unroll
+      for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
+    next_offsets();                        // 2 VALU adds in the MFMA shadow
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot + 1 == NS ? 0 : slot + 1;
+  }
+  if (!grp) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
   MT_STAMP(2);
   wait_vmcnt<0>();     // the trailing (all-zero) copies must have landed before LDS is reused / the wave exits

@@ -2,7 +2,11 @@
 import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np, torch
-from masterthesis_amd import hip_ops as ops, _lib
+import os
+from masterthesis_amd import _lib
+if os.environ.get("MT_DIAG_LIB"):          # diagnostic builds of the library (never the product path)
+    _lib.LIB_PATH = os.path.abspath(os.environ["MT_DIAG_LIB"])
+from masterthesis_amd import hip_ops as ops
 dev = torch.device('cuda:0')
 ops.set_compute_dtype(torch.bfloat16)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -12,11 +16,12 @@ with torch.no_grad():
     for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
-buf = np.zeros(8 * 4096, dtype=np.uint64)
+buf = np.zeros(16 * 4096, dtype=np.uint64)
 lib.mt_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 rc = lib.mt_debug_stamps(buf.ctypes.data, buf.nbytes)
 nb = N * 64 * 64 // 256
-s = buf.reshape(4096, 8)[:nb, :4].astype(np.int64)
+s = buf.reshape(4096, 16)[:nb, :4].astype(np.int64)
+acc = buf.reshape(4096, 16)[:nb, 8:16].astype(np.int64)
 d = np.diff(s, axis=1)
 print("rc", rc, "blocks", nb)
 print("median cycles: prologue %d  mainloop %d  epilogue %d  total %d" % tuple(list(np.median(d, axis=0)) + [np.median(s[:, 3] - s[:, 0])]))
