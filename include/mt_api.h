@@ -92,7 +92,8 @@ int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, fl
                   float* db, int n, int in, int out, mt_stream_t s);
 
 /* ---- normalisation family (K9, K10, K11): functions.py:17, norm.py:5-33 -------------- */
-/* sums[n][c] = {sum x, sum x^2} over H*W (fp32, [N][Cp][2]); overwritten. */
+/* sums[n][c] += {sum x, sum x^2} over H*W (fp32, [N][Cp][2]); the CALLER zeroes sums (fp32 atomics from
+ * several blocks per image, same contract as the stats of mt_conv_fwd_stats). */
 int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);
 /* scale/shift [N][Cp] for y = act(scale*x + shift); mean/rstd saved for backward.
  * mode INSTANCE: gamma=beta=NULL.  ADAIN: gb = fc(s) [N][2*C] (weight = 1+gb[:, :C], bias =
@@ -104,7 +105,7 @@ int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* 
 int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
                        const void* res, void* y, int N, int HW, int Cp, int act, float slope,
                        mt_stream_t s);
-/* g = dy * act'(scale*x+shift); sums2[n][c] = {sum g, sum g*x}. */
+/* g = dy * act'(scale*x+shift); sums2[n][c] += {sum g, sum g*x}; the CALLER zeroes sums2. */
 int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale,
                     const float* shift, float* sums2, int N, int HW, int Cp, int act,
                     float slope, mt_stream_t s);

@@ -253,7 +253,10 @@ static int wgrad_pixels(const mt_conv_desc* d) {
 extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
   int ns, mc;
   wgrad_split(d, wgrad_pixels(d), &ns, &mc);
-  return (size_t)ns * mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+  // split slabs of the weight gradient; reused (stream-ordered, after the unpack) for the bias-gradient partials
+  const size_t slabs = (size_t)ns * mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+  const size_t bias = mt_colsum_ws_bytes(mt_padc(d->Co));
+  return slabs > bias ? slabs : bias;
 }
 
 extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
@@ -277,7 +280,7 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
       if (mt_launch_unpack((const float*)ws, dw, u, 1, (long)Cop * Cip, accumulate, s)) return 2;
     }
     if (dbias != nullptr) {
-      if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, Cop, d->Co, accumulate, s)) return 2;
+      if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
     }
     return 0;
   }
@@ -317,7 +320,7 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
     if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, accumulate, s)) return 2;
   }
   if (dbias != nullptr) {
-    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, accumulate, s)) return 2;
+    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
   }
   return 0;
 }

@@ -681,6 +681,36 @@ __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__
     }
   }
 }
+// Many splits of a small weight tensor (stem / to-RGB layers: up to 512 slabs of ~100 KB): one WAVE per 4
+// packed columns, lanes stride over the split slabs (64 loads in flight instead of a serial chain), wave sum.
+__global__ __launch_bounds__(256) void unpack_wave_kernel(const float* __restrict__ src, float* __restrict__ dw,
+                                                          PackParams p, int nsplit, long slab, int accumulate) {
+  const int c4n = p.Cp >> 2;
+  const long total = (long)p.R * p.ntaps * c4n;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  const long rt = i / c4n;
+  const int t = (int)(rt % p.ntaps);
+  const int r = (int)(rt / p.ntaps);
+  const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < nsplit; k += 64) a += q[(long)k * (slab >> 2)];
+#pragma unroll
+  for (int e = 0; e < 4; e++) a[e] = wave_sum(a[e]);
+  if (lane == 0) {
+    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c4 * 4 + e;
+      if (c < p.C) {
+        float* o = d + (long)c * p.sc;
+        *o = accumulate ? *o + a[e] : a[e];
+      }
+    }
+  }
+}
 // Fast path (sc == ntaps, natural tap order -- every weight-gradient unpack): for a fixed row r the output
 // [c][kh][kw] is one contiguous run, so a block sums the split slabs for 64 columns with coalesced reads,
 // transposes [t][c] -> [c][t] through LDS and writes a contiguous run.
@@ -718,6 +748,9 @@ int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nspli
   // many splits keep the element-parallel kernel
   if (natural && nsplit <= 4 && (long)p.R * cdiv(p.Cp, 64) >= 512) {
     hipLaunchKernelGGL(unpack_t_kernel, dim3(p.R, cdiv(p.Cp, 64)), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  } else if (nsplit >= 32 && total <= 65536) {
+    hipLaunchKernelGGL(unpack_wave_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, src, dw, p, nsplit, slab,
+                       accumulate);
   } else {
     const int blocks = (int)min((long)4096, (total + 255) / 256);
     hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
@@ -779,13 +812,15 @@ int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, 
 }
 
 // ------------------------------------------------------------------------------------------
-// bias gradient: db[c] = sum over pixels of dy[pixel][c]   (fp32 atomics into zeroed db)
+// bias gradient: db[c] = sum over pixels of dy[pixel][c].  Two launches, no atomics (512 blocks adding into
+// the same C addresses serialise: ~100 us): blocks write fp32 partial rows, a small kernel adds them up.
 // ------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ db, long npix,
-                                                     int cchunks, int C, int pix_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ part, long npix,
+                                                     long cchunks_, long pix_per_block) {
   constexpr int V = Elem<BF16>::V;
   __shared__ float red[256];
+  const int cchunks = (int)cchunks_;
   const int cq = threadIdx.x % cchunks;
   const int pl = threadIdx.x / cchunks;
   const int npl = blockDim.x / cchunks;
@@ -795,42 +830,87 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ d
 #pragma unroll
   for (int e = 0; e < V; e++) accv[e] = 0.f;
   if (pl < npl) {
-    for (long px = p0 + pl; px < p1; px += npl) {
+    // 4 independent 16-byte loads in flight per thread (a dependent one-at-a-time loop is latency bound)
+    long px = p0 + pl;
+    for (; px + 3 * (long)npl < p1; px += 4 * (long)npl) {
+      const u32x4 v0 = dy[px * cchunks + cq];
+      const u32x4 v1 = dy[(px + npl) * cchunks + cq];
+      const u32x4 v2 = dy[(px + 2 * (long)npl) * cchunks + cq];
+      const u32x4 v3 = dy[(px + 3 * (long)npl) * cchunks + cq];
+      float f0[V], f1[V], f2[V], f3[V];
+      Elem<BF16>::unpack(v0, f0);
+      Elem<BF16>::unpack(v1, f1);
+      Elem<BF16>::unpack(v2, f2);
+      Elem<BF16>::unpack(v3, f3);
+#pragma unroll
+      for (int e = 0; e < V; e++) accv[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
+    }
+    for (; px < p1; px += npl) {
       float f[V];
       Elem<BF16>::unpack(dy[px * cchunks + cq], f);
 #pragma unroll
       for (int e = 0; e < V; e++) accv[e] += f[e];
     }
+  } else {
+    // threads beyond the last whole pixel lane contribute zeros (their tid % cchunks still names a chunk)
   }
-  // tree over the pixel lanes in LDS, then ONE atomic per (block, channel)
 #pragma unroll
   for (int e = 0; e < V; e++) {
-    __syncthreads();
-    red[threadIdx.x] = accv[e];
-    __syncthreads();
-    if (pl == 0) {
-      float a = 0.f;
-      for (int k = 0; k < npl; k++) a += red[k * cchunks + cq];
-      const int ch = cq * V + e;
-      if (ch < C) atomicAdd(db + ch, a);
-    }
+    const float a = block_sum_by_chunk(accv[e], cchunks, red);
+    if (threadIdx.x < cchunks) part[(long)blockIdx.x * cchunks * V + threadIdx.x * V + e] = a;
   }
 }
-int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, hipStream_t s) {
+// 64 channels x 16 row groups per block: the partial rows are summed 16-way in parallel (one thread walking
+// 512 rows is a 90 us dependent-load chain)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db,
+                                                            int nblk, int Cp, int C, int accumulate) {
+  __shared__ float red[1024];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int b = g;
+#pragma unroll 4
+    for (; b + 16 < nblk; b += 32) {
+      a0 += part[(long)b * Cp + c];
+      a1 += part[(long)(b + 16) * Cp + c];
+    }
+    if (b < nblk) a0 += part[(long)b * Cp + c];
+  }
+  red[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) a += red[k * 64 + cl];
+    db[c] = accumulate ? db[c] + a : a;
+  }
+}
+size_t mt_colsum_ws_bytes(int Cp) { return (size_t)512 * Cp * sizeof(float); }
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(cchunks <= 256, "colsum: too many channels %d", Cp);
-  if (!accumulate && hipMemsetAsync(db, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("colsum memset failed"); return 2; }
-  if (npix == 0) return 0;
+  MT_CHECK(ws != nullptr && ws_bytes >= mt_colsum_ws_bytes(Cp), "colsum: workspace too small");
   const int threads = 256;
   const int npl = threads / cchunks;
-  int ppb = npl * 64;  // 64 pixels per thread
-  if (ppb < 256) ppb = 256;
+  // at most 512 blocks (one row of partials each), at least 16 pixels per thread
+  long ppb = (npix + 511) / 512;
+  if (ppb < (long)npl * 16) ppb = (long)npl * 16;
+  ppb = (ppb + npl - 1) / npl * npl;
   const int blocks = (int)((npix + ppb - 1) / ppb);
-  if (dtype == MT_BF16)
-    hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, db, npix, cchunks, C, ppb);
-  else
-    hipLaunchKernelGGL((colsum_kernel<false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, db, npix, cchunks, C, ppb);
+  if (blocks > 0) {
+    if (dtype == MT_BF16)
+      hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                         (long)cchunks, ppb);
+    else
+      hipLaunchKernelGGL((colsum_kernel<false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                         (long)cchunks, ppb);
+    MT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const float*)ws, db, blocks, Cp, C,
+                     accumulate);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -82,7 +82,9 @@ int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nspli
                      hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
-int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, hipStream_t s);
+size_t mt_colsum_ws_bytes(int Cp);
+int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
+                     size_t ws_bytes, hipStream_t s);
 
 // thin 1x1 convolutions (pointwise_kernels.hip); the launchers return -1 if no instantiation matches
 struct mt_conv_desc;

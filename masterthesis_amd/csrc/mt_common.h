@@ -124,4 +124,28 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Block reduction for the streaming kernels whose threads are laid out as (pixel lane pl, 16-byte channel
+// chunk cq) with cq = tid % cchunks: sum v over the threads that share cq.  When cchunks is a power of two
+// <= 32 the lanes of a wave that share cq are first combined with xor-shuffles, so the serial tail handles one
+// partial per WAVE instead of one per thread (at cchunks = 8 and 1024 threads: 16 instead of 128 LDS reads per
+// output).  `red` needs blockDim.x floats.  The total is returned to the thread with tid < cchunks (others: 0).
+__device__ __forceinline__ float block_sum_by_chunk(float v, int cchunks, float* red) {
+  const int tid = threadIdx.x;
+  const bool pow2 = (cchunks & (cchunks - 1)) == 0;
+  int stride = cchunks;
+  if (pow2 && cchunks < 64) {
+    for (int o = cchunks; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    stride = 64;
+  }
+  __syncthreads();
+  red[tid] = v;
+  __syncthreads();
+  float a = 0.f;
+  if (tid < cchunks) {
+    const int cnt = blockDim.x / stride;
+    for (int k = 0; k < cnt; k++) a += red[tid + k * stride];
+  }
+  return a;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -40,12 +40,12 @@ __global__ __launch_bounds__(1024) void nc_stats_kernel(const u32x4* __restrict_
     }
   }
   if (pl < npl) {
-    for (int px = p0 + pl; px < p1; px += npl) {
+    auto accum = [&](const u32x4& xv, const u32x4& gv) {
       float f[V];
-      Elem<BF16>::unpack(x[base + (long)px * cchunks + cq], f);
+      Elem<BF16>::unpack(xv, f);
       if constexpr (BWD) {
         float g[V];
-        Elem<BF16>::unpack(dy[base + (long)px * cchunks + cq], g);
+        Elem<BF16>::unpack(gv, g);
 #pragma unroll
         for (int e = 0; e < V; e++) {
           const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
@@ -56,19 +56,32 @@ __global__ __launch_bounds__(1024) void nc_stats_kernel(const u32x4* __restrict_
 #pragma unroll
         for (int e = 0; e < V; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
       }
+    };
+    // two pixels per iteration: 2 (4 backward) independent 16-byte loads in flight per thread
+    int px = p0 + pl;
+    for (; px + npl < p1; px += 2 * npl) {
+      const long i0 = base + (long)px * cchunks + cq, i1 = i0 + (long)npl * cchunks;
+      const u32x4 xa = x[i0], xb = x[i1];
+      u32x4 ga = xa, gb = xb;
+      if constexpr (BWD) { ga = dy[i0]; gb = dy[i1]; }
+      accum(xa, ga);
+      accum(xb, gb);
+    }
+    if (px < p1) {
+      const long i0 = base + (long)px * cchunks + cq;
+      const u32x4 xa = x[i0];
+      u32x4 ga = xa;
+      if constexpr (BWD) ga = dy[i0];
+      accum(xa, ga);
     }
   }
-  // reduce over pixel lanes through LDS, one element at a time (small: V*2 rounds)
+  // reduce over the pixel lanes (shuffles inside a wave, LDS across waves), then one atomic per (block, channel)
 #pragma unroll
   for (int e = 0; e < V; e++) {
-    __syncthreads();
-    red[threadIdx.x * 2] = s1[e];
-    red[threadIdx.x * 2 + 1] = s2[e];
-    __syncthreads();
-    if (pl == 0) {
-      float a = 0.f, b = 0.f;
-      for (int k = 0; k < npl; k++) { a += red[(k * cchunks + cq) * 2]; b += red[(k * cchunks + cq) * 2 + 1]; }
-      float* dst = sums + ((long)n * Cp + cq * V + e) * 2;
+    const float a = block_sum_by_chunk(s1[e], cchunks, red);
+    const float b = block_sum_by_chunk(s2[e], cchunks, red);
+    if (threadIdx.x < cchunks) {
+      float* dst = sums + ((long)n * Cp + threadIdx.x * V + e) * 2;
       atomicAdd(dst, a);
       atomicAdd(dst + 1, b);
     }
@@ -81,15 +94,15 @@ static int launch_stats(int dtype, const void* x, const void* dy, const float* s
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(Cp % 8 == 0 && cchunks >= 1 && cchunks <= 256, "nc_stats: unsupported channel count %d", Cp);
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)N * Cp, s) != hipSuccess) {
-    mt_set_error("nc_stats: memset failed");
-    return 2;
-  }
+  // sums is accumulated into with atomics: the caller zeroes it (same contract as mt_conv_fwd_stats)
   // 1024-thread blocks (16 waves per CU in flight for the HBM stream), 8 pixels per thread
   const int NT = 1024;
   const int npl = NT / cchunks;
   int ppb = npl * 8;
   if (ppb < 64) ppb = 64;
+  // large maps: about one round of 512 resident blocks (fewer block reductions and atomics per byte streamed)
+  const long want = ((long)N * HW + 511) / 512;
+  if (want > ppb) ppb = (int)min((long)HW, (want + npl - 1) / npl * npl);
   dim3 grid(cdiv(HW, ppb), N);
   if (dtype == MT_BF16)
     hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(NT), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);

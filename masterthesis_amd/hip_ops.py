@@ -54,6 +54,69 @@ def _need_hip(t):
                            f"got a tensor on {t.device}")
 
 
+class _ZeroArena:
+    """fp32 scratch that is zero when handed out: ONE memset per training-step scope instead of one fill kernel
+    per statistics buffer (~250 of them per AdaINModel step).  Only transient buffers that are consumed inside
+    the scope may come from here; outside a scope (inference, unit tests) ``take`` is a plain ``torch.zeros``."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = self.dirty = self.need = self.asked = self.depth = 0
+
+    def begin(self, device):
+        self.depth += 1
+        if self.depth > 1:
+            return
+        want = max(self.need, 1 << 18)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < want:
+            self.buf = torch.zeros(int(want * 1.25), dtype=torch.float32, device=device)
+        elif self.dirty:
+            self.buf[:self.dirty].zero_()
+        self.off = self.dirty = self.asked = 0
+
+    def end(self):
+        self.depth -= 1
+        if self.depth == 0:
+            self.need = max(self.need, self.asked)
+            self.dirty = self.off
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) & ~63
+        self.asked += n_al
+        if self.depth == 0 or self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        return t
+
+
+_arena = _ZeroArena()
+
+
+def step_scope(fn):
+    """Decorator for the model's ``update_*`` methods: zero-scratch hand-outs inside share one memset."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if dev is None:
+            return fn(self, *a, **kw)
+        _arena.begin(dev)
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            _arena.end()
+    return wrapped
+
+
+def _zero_stats(shape, device):
+    return _arena.take(shape, device)
+
+
 def new_act(N, Cc, H, W, dtype, device, zero=False):
     """Allocate a canonical activation and return its logical NCHW view."""
     alloc = torch.zeros if zero else torch.empty
@@ -207,7 +270,7 @@ class _Conv(torch.autograd.Function):
         pack = _get_pack(owner, weight, desc, L.PACK_FWD)
         b = None if bias is None else _f32c(bias.detach())
         # normalisation statistics of the output are accumulated (atomics) in the GEMM epilogue
-        sums = torch.zeros((N, padc(Co), 2), dtype=torch.float32, device=x.device) if want_stats else None
+        sums = _zero_stats((N, padc(Co), 2), x.device) if want_stats else None
         timed = _KTIMER["match"] is not None and _KTIMER["match"](desc)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -344,7 +407,7 @@ class _Norm(torch.autograd.Function):
         dev = x.device
         mt = _mt(x.dtype)
         if sums is None:
-            sums = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
+            sums = _zero_stats((N, Cp, 2), dev)
             L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
         elif tuple(sums.shape) != (N, Cp, 2):
             raise RuntimeError(f"norm: precomputed statistics have shape {tuple(sums.shape)}, expected {(N, Cp, 2)}")
@@ -376,7 +439,7 @@ class _Norm(torch.autograd.Function):
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
-        sums2 = torch.empty((N, Cp, 2), dtype=torch.float32, device=dev)
+        sums2 = _zero_stats((N, Cp, 2), dev)
         L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
                                     slope, _stream()), "mt_nc_stats_bwd")
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)

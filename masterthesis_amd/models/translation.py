@@ -125,6 +125,7 @@ class TranslationModel(Model):
         return (ops.cat_batch((img_ba, img_ab)), ops.cat_batch((img_br, img_ar)), ops.cat_batch((img_aa, img_bb)))
 
     # ---- content discriminator (optional; reference adain_model.py:136-144, 334-337) ---------------
+    @ops.step_scope
     def update_content_discriminator(self, img, c_org):
         with torch.no_grad():
             z_c = self.model.content_encoder(img)
@@ -145,6 +146,7 @@ class TranslationModel(Model):
         return self.classification_loss(pred, 1 - self.c_org)
 
     # ---- PHASE 1-2 ----------------------------------------------------------------------------------
+    @ops.step_scope
     def update_discriminator(self, img, c_org):
         B = self.args.batch_size
         cls_a, cls_b = torch.split(c_org, B, dim=0)
@@ -184,6 +186,7 @@ class TranslationModel(Model):
     backward_multi_scale_discriminator = backward_discriminator
 
     # ---- PHASE 3-4 ----------------------------------------------------------------------------------
+    @ops.step_scope
     def update_generator(self, img, c_org):
         for n in ("content_encoder", "style_encoder", "decoder"):
             self.optimizer[n].zero_grad()
