@@ -55,9 +55,46 @@ static inline bool phased(const mt_conv_desc* d, int which) {
   return d->transposed ? (which == MT_PACK_FWD) : (which == MT_PACK_BWD_DATA);
 }
 
+// ---- stride-1 reflect-padded Conv2d data gradient ("interior + ring") -------------------------------------
+// dx = fold(dxp), dxp = full correlation of dy on the padded (H+2P)x(W+2P) grid.  Computing all of dxp wastes a
+// ragged grid (K1: 1090 tiles of 128x128 = 2.13 rounds of the chip); instead
+//   (1) the interior pre-image dxp[h+P][w+P] is written straight into dx (an HxW grid: K1 = 256 tiles of the
+//       256x256 ping-pong kernel, exactly one round),
+//   (2) the four P-wide border strips of dxp go to the workspace -- only the filter taps that can reach dy
+//       from there (P*kw resp. kh*P of the kh*kw taps) -- and
+//   (3) ring_fold adds them onto the border band of dx.
+// The data-gradient weight pack therefore carries the tap runs [all | top | bottom | left | right] in ONE image
+// (rows of T taps); a launch phase addresses its run through IgemmPhase::{w_off, wrow}.
+struct RingTaps {
+  int total;               // taps in the pack image
+  int start[5], count[5];  // runs: 0 all, 1 top, 2 bottom, 3 left, 4 right
+  short kh[MT_MAX_TAPS], kw[MT_MAX_TAPS];
+};
+static bool ring_taps(const mt_conv_desc* d, RingTaps* r) {
+  if (d->transposed || d->pad_mode != MT_PAD_REFLECT || d->pad == 0 || d->stride != 1 || mt_pointwise_small(d))
+    return false;
+  const int P = d->pad;
+  int n = 0;
+  for (int run = 0; run < 5; run++) {
+    r->start[run] = n;
+    for (int a = 0; a < d->kh; a++)
+      for (int b = 0; b < d->kw; b++) {
+        const bool use = run == 0 || (run == 1 && a <= P - 1) || (run == 2 && a >= d->kh - P) ||
+                         (run == 3 && b <= P - 1) || (run == 4 && b >= d->kw - P);
+        if (!use) continue;
+        if (n >= MT_MAX_TAPS) return false;   // (7x7 stem: the padded-grid path stays)
+        r->kh[n] = (short)a; r->kw[n] = (short)b; n++;
+      }
+    r->count[run] = n - r->start[run];
+  }
+  r->total = n;
+  return true;
+}
+
 extern "C" size_t mt_conv_pack_bytes(const mt_conv_desc* d, int which) {
-  (void)which;
-  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * esz(d->dtype);
+  RingTaps r;
+  const int taps = (which == MT_PACK_BWD_DATA && ring_taps(d, &r)) ? r.total : d->kh * d->kw;
+  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * taps * esz(d->dtype);
 }
 
 // taps of phase (ph, pw) in (kh, kw) order
@@ -86,6 +123,13 @@ extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, vo
   else { p.R = d->Ci; p.C = d->Co; p.sr = s_ci; p.sc = s_co; }
   p.Rp = mt_padc(p.R);
   p.Cp = mt_padc(p.C);
+  RingTaps rt;
+  if (which == MT_PACK_BWD_DATA && ring_taps(d, &rt)) {
+    p.ntaps = rt.total;
+    memcpy(p.kh, rt.kh, sizeof(short) * rt.total);
+    memcpy(p.kw, rt.kw, sizeof(short) * rt.total);
+    return mt_launch_pack(d->dtype, w, pack, p, s);
+  }
   if (!phased(d, which)) {
     p.ntaps = K2;
     for (int a = 0; a < d->kh; a++)
@@ -130,6 +174,7 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
       const int Wg = o0w < Wd ? (Wd - o0w + st - 1) / st : 0;
       IgemmPhase& q = p.ph[p.nphase];
       q.w_off = (unsigned)w_off; q.ntaps = nt; q.tap0 = tap0;
+      q.wrow = nt * p.cpc; q.w_bytes = (unsigned)((size_t)Cout_p * nt * Cin_p * sz);
       q.Ho = Hg; q.Wo = Wg; q.M = d->N * Hg * Wg; q.oh0 = o0h; q.ow0 = o0w;
       for (int t = 0; t < nt; t++) {
         p.dh[tap0 + t] = (short)((o0h + e - kh[t]) / st);
@@ -161,6 +206,7 @@ static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, 
   p.nphase = 1;
   IgemmPhase& q = p.ph[0];
   q.w_off = 0; q.ntaps = d->kh * d->kw; q.tap0 = 0; q.Ho = Hg; q.Wo = Wg; q.M = d->N * Hg * Wg; q.oh0 = 0; q.ow0 = 0;
+  q.wrow = q.ntaps * p.cpc; q.w_bytes = (unsigned)((size_t)Cout_p * q.ntaps * Cin_p * sz);
   for (int a = 0; a < d->kh; a++)
     for (int b = 0; b < d->kw; b++) {
       p.dh[a * d->kw + b] = (short)(a - d->pad);
@@ -224,6 +270,48 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   if (P == 0)
     return scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, d->pad, MT_ACT_NONE, s);
   MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_data_ws_bytes(d), "conv_bwd_data: workspace too small");
+  RingTaps rt;
+  if (ring_taps(d, &rt)) {
+    const int sz = esz(d->dtype), V = vec(d->dtype);
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)dy; p.w = (const char*)pack_bwd; p.N = d->N; p.Hi = Ho; p.Wi = Wo; p.Cib = Cop * sz;
+    p.Co = Cip; p.CoRows = Cip; p.os = 1; p.is = 1; p.cpc = Cop / V;
+    p.pad_mode = MT_PAD_ZERO; p.act = MT_ACT_NONE; p.slope = d->slope;
+    const size_t image = (size_t)Cip * rt.total * Cop * sz;
+    auto phase = [&](int run, int oh0, int ow0, int Hs, int Ws) {
+      if (rt.count[run] == 0 || Hs <= 0 || Ws <= 0) return;
+      IgemmPhase& q = p.ph[p.nphase];
+      int tap0 = 0;
+      for (int i = 0; i < p.nphase; i++) tap0 += p.ph[i].ntaps;
+      q.ntaps = rt.count[run]; q.tap0 = tap0;
+      q.w_off = (unsigned)((size_t)rt.start[run] * Cop * sz); q.w_bytes = (unsigned)(image - q.w_off);
+      q.wrow = rt.total * p.cpc;
+      q.Ho = Hs; q.Wo = Ws; q.M = d->N * Hs * Ws; q.oh0 = oh0; q.ow0 = ow0;
+      // padded-grid pixel (ho + oh0, wo + ow0) reads dy[(ho + oh0) - a][(wo + ow0) - b]
+      for (int t = 0; t < q.ntaps; t++) {
+        p.dh[tap0 + t] = (short)(oh0 - rt.kh[rt.start[run] + t]);
+        p.dw[tap0 + t] = (short)(ow0 - rt.kw[rt.start[run] + t]);
+      }
+      p.nphase++;
+    };
+    // (1) interior: output pixel (h, w) is padded pixel (h + P, w + P); reuse `phase` with the offset folded
+    //     into the tap table and no output offset
+    p.y = (char*)dx; p.Hout = d->H; p.Wout = d->W;
+    phase(0, 0, 0, d->H, d->W);
+    for (int t = 0; t < p.ph[0].ntaps; t++) { p.dh[t] = (short)(p.dh[t] + P); p.dw[t] = (short)(p.dw[t] + P); }
+    if (mt_launch_igemm(d->dtype, p, s)) return 2;
+    // (2) the four strips of the ring, into the padded workspace
+    p.nphase = 0;
+    p.y = (char*)ws; p.Hout = d->H + 2 * P; p.Wout = d->W + 2 * P;
+    phase(1, 0, 0, P, d->W + 2 * P);
+    phase(2, d->H + P, 0, P, d->W + 2 * P);
+    phase(3, P, 0, d->H, P);
+    phase(4, P, d->W + P, d->H, P);
+    if (p.nphase > 0 && mt_launch_igemm(d->dtype, p, s)) return 2;
+    // (3) fold the ring onto the border band
+    return mt_launch_ring_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
+  }
   if (scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s))
     return 2;
   return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
     const int row = wt * WT + rl;
     const bool ok = (rl < WT) && (row < p.CoRows);
     wokm |= (ok ? 1u : 0u) << i;
-    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)ph_nchunks + (unsigned)c) * 16u;
+    wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)ph.wrow + (unsigned)c) * 16u;
   }
   static_assert(NXL == 4, "every geometry stages 4 pixel rows per thread");
   unsigned xo32[4];   // (literal size: hipcc 7.2 drops the host stub when this lambda-captured array is NXL-sized)
@@ -134,8 +134,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   };
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, (unsigned)p.CoRows * (unsigned)ph_nchunks * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, ph.w_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   // The asynchronous global->LDS copies of the next k-step are issued ONE instruction at a time,
   // interleaved with the MFMA groups of the current k-step (an LDS-DMA instruction costs ~60-180 issue
@@ -328,7 +327,7 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
   // (the ping-pong kernel steps whole 4-chunk k-steps inside a tap and marks zero lanes with offsets >= 2 GiB)
   const bool pipe_ok = p.cpc % 4 == 0 && p.ph[0].ntaps <= 25 /* MT_PIPE_MAX_TAPS */ && p.x_bytes < 0x7f000000u &&
-                       (double)p.CoRows * p.ph[0].ntaps * p.cpc * 16.0 < (double)0x7f000000u;
+                       p.ph[0].w_bytes < 0x7f000000u;
   if (p.nphase == 1 && p.CoRows % 256 == 0 && pipe_ok) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
     if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
@@ -354,10 +353,12 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(p.nphase >= 1 && p.nphase <= MT_MAX_PHASES, "igemm: bad phase count %d", p.nphase);
   MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
   MT_CHECK((double)p.N * p.Hi * p.Wi * p.Cib < 4294967000.0, "igemm: input tensor exceeds 4 GiB (32-bit offsets)");
-  double wbytes = 0;
   int taps = 0;
-  for (int i = 0; i < p.nphase; i++) { wbytes += (double)p.CoRows * p.ph[i].ntaps * p.cpc * 16.0; taps += p.ph[i].ntaps; }
-  MT_CHECK(wbytes < 4294967000.0, "igemm: weight pack exceeds 4 GiB");
+  for (int i = 0; i < p.nphase; i++) {
+    MT_CHECK(p.ph[i].wrow >= p.ph[i].ntaps * p.cpc, "igemm: weight row shorter than the phase's taps");
+    MT_CHECK((double)p.ph[i].w_off + (double)p.ph[i].w_bytes < 4294967000.0, "igemm: weight pack exceeds 4 GiB");
+    taps += p.ph[i].ntaps;
+  }
   MT_CHECK(taps <= MT_MAX_TAPS, "igemm: %d taps > %d", taps, MT_MAX_TAPS);
   IgemmParams q = p;
   q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
@@ -807,6 +808,75 @@ int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, 
     hipLaunchKernelGGL((reflect_fold_kernel<true>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
   else
     hipLaunchKernelGGL((reflect_fold_kernel<false>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// Border-only variant for the stride-1 path: dst already holds the interior part (pre-image (h+P, w+P)); add
+// the other pre-images, which all lie in the P-wide ring of the padded map.  Only pixels within P of a border
+// (excluding the outermost row / column, which reflection never hits) have any.
+template <bool BF16>
+__global__ void ring_fold_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H, int W,
+                                 int cchunks, int P, int band) {
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  // band != 0 (H, W >= 2P+2): enumerate only the pixels that have a ring pre-image -- 2P full rows, then 2P
+  // columns of the remaining H-2P rows; otherwise scan every pixel
+  const int nrowpix = 2 * P * W;
+  const int per_img = band ? nrowpix + (H - 2 * P) * 2 * P : H * W;
+  const long total = (long)N * per_img * cchunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cchunks);
+    long t = i / cchunks;
+    const int j = (int)(t % per_img);
+    const int n = (int)(t / per_img);
+    int h, w;
+    if (!band) {
+      h = j / W; w = j - h * W;
+    } else if (j < nrowpix) {
+      const int r = j / W;
+      w = j - r * W;
+      h = r < P ? 1 + r : H - 1 - P + (r - P);
+    } else {
+      const int jj = j - nrowpix;
+      const int rr = jj / (2 * P), wc = jj - rr * (2 * P);
+      h = rr == 0 ? 0 : (rr == H - 2 * P - 1 ? H - 1 : P + rr);
+      w = wc < P ? 1 + wc : W - 1 - P + (wc - P);
+    }
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + P;
+    if (h >= 1 && h <= P) hs[nh++] = P - h;
+    if (h <= H - 2 && h >= H - 1 - P) hs[nh++] = P + 2 * (H - 1) - h;
+    ws[nw++] = w + P;
+    if (w >= 1 && w <= P) ws[nw++] = P - w;
+    if (w <= W - 2 && w >= W - 1 - P) ws[nw++] = P + 2 * (W - 1) - w;
+    if (nh * nw == 1) continue;
+    const long di = (((long)n * H + h) * W + w) * cchunks + cq;
+    float accv[Elem<BF16>::V];
+    Elem<BF16>::unpack(dst[di], accv);
+    for (int a = 0; a < nh; a++)
+      for (int b = 0; b < nw; b++) {
+        if (a == 0 && b == 0) continue;
+        const u32x4 v = src[(((long)n * Hp + hs[a]) * Wp + ws[b]) * cchunks + cq];
+        float f[Elem<BF16>::V];
+        Elem<BF16>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < Elem<BF16>::V; e++) accv[e] += f[e];
+      }
+    dst[di] = Elem<BF16>::pack(accv);
+  }
+}
+int mt_launch_ring_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P, hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  const int band = (H >= 2 * P + 2 && W >= 2 * P + 2) ? 1 : 0;
+  const long per_img = band ? (long)2 * P * W + (long)(H - 2 * P) * 2 * P : (long)H * W;
+  const long total = (long)N * per_img * cchunks;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)65535, (total + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((ring_fold_kernel<true>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P, band);
+  else
+    hipLaunchKernelGGL((ring_fold_kernel<false>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P, band);
   MT_LAUNCH_CHECK();
   return 0;
 }

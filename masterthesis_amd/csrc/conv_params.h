@@ -13,7 +13,10 @@
 // output offset.  All phases run in ONE launch (blocks [blk0, blk0+nblk) belong to a phase), so the
 // dispatcher balances them instead of paying a ragged last round of blocks per phase.
 struct IgemmPhase {
-  unsigned w_off;     // byte offset of this phase's weight pack
+  unsigned w_off;     // byte offset of this phase's first weight chunk (row 0) from IgemmParams::w
+  unsigned w_bytes;   // bytes of the weight image that are addressable from there (buffer range check)
+  int wrow;           // 16-byte chunks per row of the weight image (>= ntaps*cpc: a phase may use a run of
+                      // consecutive taps of a wider image)
   int ntaps, tap0;    // taps [tap0, tap0+ntaps) of the dh/dw tables
   int Ho, Wo, M;      // GEMM pixel grid of the phase, M = N*Ho*Wo
   int oh0, ow0;       // output pixel = (ho*os + oh0, wo*os + ow0)
@@ -82,6 +85,7 @@ int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nspli
                      hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
+int mt_launch_ring_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P, hipStream_t s);
 size_t mt_colsum_ws_bytes(int Cp);
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
                      size_t ws_bytes, hipStream_t s);

@@ -133,13 +133,12 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
     // channel held by that row: within each 32-row fragment pair, row (a&1)*16 + r <- channel (r>>2)*8 + (a&1)*4 + (r&3)
     const int rl = (rs & ~31) | ((((rs & 15) >> 2) << 3) | (((rs >> 4) & 1) << 2) | (rs & 3));
     const int row = wt * WT + rl;
-    wo32[i] = row < p.CoRows ? ((unsigned)row * (unsigned)ph_nchunks + (unsigned)c) * 16u : OOB;
+    wo32[i] = row < p.CoRows ? ((unsigned)row * (unsigned)ph.wrow + (unsigned)c) * 16u : OOB;
   }
   int tap_s = 0, cqb = 0;       // wave-uniform: filter tap and first chunk inside it of the NEXT stage to issue
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, (unsigned)p.CoRows * (unsigned)ph_nchunks * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, ph.w_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   char* const lds0 = reinterpret_cast<char*>(&smem[0]);
 

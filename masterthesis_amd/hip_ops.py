@@ -243,6 +243,42 @@ def kernel_timer_stop():
     return out
 
 
+_OPLOG = {"on": False, "events": []}
+
+
+def oplog_start():
+    """Record HIP events around every conv forward / data-gradient / weight-gradient call (tools/layer_table.py)."""
+    _OPLOG["on"] = True
+    _OPLOG["events"] = []
+
+
+def oplog_stop():
+    """-> list of (kind, descriptor tuple, milliseconds)."""
+    _OPLOG["on"] = False
+    torch.cuda.synchronize()
+    out = [(k, d, a.elapsed_time(b)) for k, d, a, b in _OPLOG["events"]]
+    _OPLOG["events"] = []
+    return out
+
+
+class _oplog:
+    def __init__(self, kind, desc, extra=()):
+        self.on = _OPLOG["on"]
+        if self.on:
+            self.key = (kind, tuple(getattr(desc, f[0]) for f in desc._fields_) + tuple(extra))
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _OPLOG["events"].append((self.key[0], self.key[1], self.e0, e1))
+
+
 # --------------------------------------------------------------------------------------
 # convolution family
 # --------------------------------------------------------------------------------------
@@ -275,11 +311,13 @@ class _Conv(torch.autograd.Function):
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if want_stats:
-            L.check(lib.mt_conv_fwd_stats(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(sums), _stream()),
-                    "mt_conv_fwd_stats")
-        else:
-            L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()), "mt_conv_fwd")
+        with _oplog("fwd", desc, (int(want_stats),)):
+            if want_stats:
+                L.check(lib.mt_conv_fwd_stats(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(sums),
+                                              _stream()), "mt_conv_fwd_stats")
+            else:
+                L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()),
+                        "mt_conv_fwd")
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -312,8 +350,9 @@ class _Conv(torch.autograd.Function):
             nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dy.device)
             dx = new_act(*x.shape, dy.dtype, dy.device)
-            L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
-                    "mt_conv_bwd_data")
+            with _oplog("dgrad", desc):
+                L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
+                        "mt_conv_bwd_data")
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
@@ -328,14 +367,16 @@ class _Conv(torch.autograd.Function):
             gb = fused_target(ctx.bias_owner) if want_b else None
             if gw is not None and (gb is not None or not want_b):
                 # accumulate in place; autograd gets None for both
-                L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), _ptr(ws), nws, 1,
-                                               _stream()), "mt_conv_bwd_weight")
+                with _oplog("wgrad", desc, (int(want_b),)):
+                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), _ptr(ws), nws,
+                                                   1, _stream()), "mt_conv_bwd_weight")
             else:
                 dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
                 if want_b:
                     db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
-                L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, 0,
-                                               _stream()), "mt_conv_bwd_weight")
+                with _oplog("wgrad", desc, (int(want_b),)):
+                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
+                                                   0, _stream()), "mt_conv_bwd_weight")
         return dx, dw, db, None
 
 
