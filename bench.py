@@ -185,8 +185,8 @@ def main():
                    "step_tflop_algorithmic": round(f_step, 2),
                    "step_tflops_achieved_per_gpu": round(f_step / (ms_per_step * 1e-3), 1),
                    "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4)},
-        "roofline": {"bound": "mfma", "kernel": ("igemm_kernel<bf16,256,256,512>" if o.precision == "bf16" else
-                                                 "igemm_kernel<f32,256,256,512>") + " fwd 3x3 s1 256->256 @64x64 "
+        "roofline": {"bound": "mfma", "kernel": ("igemm_pipe_kernel<bf16,256,256,512,4>" if o.precision == "bf16" else
+                                                 "igemm_pipe_kernel<f32,256,256,512,4>") + " fwd 3x3 s1 256->256 @64x64 "
                                                 "(+ fused InstanceNorm-statistics epilogue)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,

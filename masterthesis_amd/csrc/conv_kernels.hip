@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int b = 0; b < 4; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
         }
       }
@@ -576,30 +576,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int a = 0; a < 4; a++)
 #pragma unroll
           for (int b = 0; b < 4; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b], af[a], acc[a][b], 0, 0, 0);
       }
     }
   };
   for (int ks = 0; ks + 1 < nk; ks++) kstep(ks & 1, std::true_type{});
   kstep((nk - 1) & 1, std::false_type{});
 
-  // epilogue: D[row = a-channel (lane>>4)*4+j][col = lane&15] -> this split's own fp32 slab (plain stores;
-  // the splits are summed by unpack_kernel -- cheaper than 1.3 TB/s fp32 atomics at 20+ splits)
+  // epilogue: the MFMAs ran with the column operand as A, so a lane holds D[col = (lane>>4)*4 + j][a-channel =
+  // lane&15]: 4 CONSECUTIVE columns of one output row -> one 16-byte store per fragment into this split's own
+  // fp32 slab (the splits are summed by unpack_kernel -- cheaper than 1.3 TB/s fp32 atomics at 20+ splits)
   const int fr = lane & 15, fg = lane >> 4;
-  const int ncols = p.nchunks * V;
+  const int ncols = p.nchunks * V;     // multiple of 4
   float* slab = p.out + (size_t)split * p.CaRows * ncols;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
+    const int ca = at * 128 + waI * 64 + a * 16 + fr;
+    if (ca >= p.CaRows) continue;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int ca = at * 128 + waI * 64 + a * 16 + fg * 4 + j;
-      if (ca >= p.CaRows) continue;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int col = bt * 128 + wbI * 64 + b * 16 + fr;
-        if (col >= ncols) continue;
-        slab[(size_t)ca * ncols + col] = acc[a][b][j];
-      }
+    for (int b = 0; b < 4; b++) {
+      const int col = bt * 128 + wbI * 64 + b * 16 + fg * 4;
+      if (col >= ncols) continue;
+      *reinterpret_cast<f32x4*>(slab + (size_t)ca * ncols + col) = acc[a][b];
     }
   }
 }

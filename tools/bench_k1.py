@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from masterthesis_amd import hip_ops as ops
 dev = torch.device('cuda:0')

@@ -1,6 +1,7 @@
 """In-kernel s_memtime stamps of the 256x256 gather-GEMM (diagnostic build: make -C masterthesis_amd/csrc STAMPS=1)."""
 import sys, ctypes as C
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import os
 from masterthesis_amd import _lib
