@@ -40,7 +40,14 @@ def _mt(dtype):
     return L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of the current HIP stream (the C ABI takes the stream explicitly).  The private torch call is
+    ~10x cheaper than ``torch.cuda.current_stream()`` (3.5k calls per training step)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
