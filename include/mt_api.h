@@ -65,6 +65,14 @@ int mt_conv_out_hw(const mt_conv_desc* d, int* Ho, int* Wo);
 size_t mt_conv_pack_bytes(const mt_conv_desc* d, int which);
 /* w: reference-layout fp32 weights.  pack: mt_conv_pack_bytes() bytes. */
 int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, mt_stream_t s);
+/* Batched pack of n (descriptor, which, weights, pack buffer) tuples in ONE launch (a network's weights after its
+ * optimizer step).  _build fills a HOST table of mt_conv_pack_multi_table_bytes(n) bytes; the caller copies it to
+ * device memory once (the addresses in it must stay valid) and calls _run with that copy whenever the weights
+ * changed.  Same images as mt_conv_pack. */
+size_t mt_conv_pack_multi_table_bytes(int n);
+int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const int* which, const float* const* w,
+                             void* const* packs, void* host_table, int* n_entries, int* total_blocks);
+int mt_conv_pack_multi_run(const void* dev_table, int n_entries, int total_blocks, mt_stream_t s);
 /* y = act(conv(x) + bias).  bias may be NULL (length Co, fp32). */
 int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                 void* y, mt_stream_t s);

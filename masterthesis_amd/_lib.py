@@ -40,6 +40,9 @@ SIGNATURES = {
     "mt_conv_out_hw": (_i, [_dp, C.POINTER(_i), C.POINTER(_i)]),
     "mt_conv_pack_bytes": (_z, [_dp, _i]),
     "mt_conv_pack": (_i, [_dp, _i, _p, _p, _p]),
+    "mt_conv_pack_multi_table_bytes": (_z, [_i]),
+    "mt_conv_pack_multi_build": (_i, [_i, _p, _p, _p, _p, _p, C.POINTER(_i), C.POINTER(_i)]),
+    "mt_conv_pack_multi_run": (_i, [_p, _i, _i, _p]),
     "mt_conv_fwd": (_i, [_dp, _p, _p, _p, _p, _p]),
     "mt_conv_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _p, _p]),
     "mt_conv_bwd_data_ws_bytes": (_z, [_dp]),

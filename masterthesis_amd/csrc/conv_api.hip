@@ -106,9 +106,10 @@ static int phase_taps(const mt_conv_desc* d, int ph, int pw, short* kh, short* k
   return n;
 }
 
-extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, mt_stream_t st) {
-  if (check_desc(d)) return 1;
-  hipStream_t s = (hipStream_t)st;
+// The pack images of one (descriptor, which): 1 for the gather form and the ring image, stride^2 for the scatter form.
+// emit(PackParams, byte offset into `pack`) is called per image.
+template <class F>
+static int pack_images(const mt_conv_desc* d, int which, F emit) {
   const int K2 = d->kh * d->kw;
   PackParams p;
   memset(&p, 0, sizeof(p));
@@ -128,23 +129,62 @@ extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, vo
     p.ntaps = rt.total;
     memcpy(p.kh, rt.kh, sizeof(short) * rt.total);
     memcpy(p.kw, rt.kw, sizeof(short) * rt.total);
-    return mt_launch_pack(d->dtype, w, pack, p, s);
+    return emit(p, (size_t)0);
   }
   if (!phased(d, which)) {
     p.ntaps = K2;
     for (int a = 0; a < d->kh; a++)
       for (int b = 0; b < d->kw; b++) { p.kh[a * d->kw + b] = (short)a; p.kw[a * d->kw + b] = (short)b; }
-    return mt_launch_pack(d->dtype, w, pack, p, s);
+    return emit(p, (size_t)0);
   }
-  char* out = (char*)pack;
+  size_t off = 0;
   for (int ph = 0; ph < d->stride; ph++)
     for (int pw = 0; pw < d->stride; pw++) {
       p.ntaps = phase_taps(d, ph, pw, p.kh, p.kw);
       if (p.ntaps == 0) continue;
-      if (mt_launch_pack(d->dtype, w, out, p, s)) return 2;
-      out += (size_t)p.Rp * p.ntaps * p.Cp * esz(d->dtype);
+      if (emit(p, off)) return 2;
+      off += (size_t)p.Rp * p.ntaps * p.Cp * esz(d->dtype);
     }
   return 0;
+}
+
+extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  return pack_images(d, which, [&](const PackParams& p, size_t off) {
+    return mt_launch_pack(d->dtype, w, (char*)pack + off, p, s);
+  });
+}
+
+// ---- batched pack: all weight images of a network in one launch ----------------------------------------------
+// mt_conv_pack_multi_build fills a HOST table (the caller copies it to the device once; weight and pack addresses
+// are stable across steps), mt_conv_pack_multi_run launches over the device copy.
+extern "C" size_t mt_conv_pack_multi_table_bytes(int n) { return (size_t)n * MT_MAX_PHASES * sizeof(PackEntry); }
+extern "C" int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const int* which, const float* const* w,
+                                        void* const* packs, void* host_table, int* n_entries, int* total_blocks) {
+  PackEntry* tab = (PackEntry*)host_table;
+  int ne = 0, blocks = 0;
+  for (int i = 0; i < n; i++) {
+    const mt_conv_desc* d = &descs[i];
+    if (check_desc(d)) return 1;
+    const int rc = pack_images(d, which[i], [&](const PackParams& p, size_t off) {
+      const long total = (long)p.Rp * p.ntaps * p.Cp;
+      if (total == 0) return 0;
+      PackEntry& e = tab[ne++];
+      e.p = p; e.w = w[i]; e.out = (char*)packs[i] + off; e.bf16 = d->dtype == MT_BF16;
+      e.blk0 = blocks;
+      e.nblk = (int)(total + 255) / 256 < 2048 ? (int)((total + 255) / 256) : 2048;
+      blocks += e.nblk;
+      return 0;
+    });
+    if (rc) return rc;
+  }
+  *n_entries = ne;
+  *total_blocks = blocks;
+  return 0;
+}
+extern "C" int mt_conv_pack_multi_run(const void* dev_table, int n_entries, int total_blocks, mt_stream_t st) {
+  return mt_launch_pack_multi((const PackEntry*)dev_table, n_entries, total_blocks, (hipStream_t)st);
 }
 
 // scatter-form launches shared by Conv2d bwd_data and ConvTranspose2d fwd.

@@ -646,6 +646,34 @@ __global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out,
     else reinterpret_cast<float*>(out)[i] = v;
   }
 }
+// batched variant: the table lives in device memory (built once per network, addresses are stable)
+__global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;                       // entry whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= tab[mid].blk0) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry& e = tab[lo];
+  const PackParams& p = e.p;
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  const float* __restrict__ w = e.w;
+  for (long i = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; i < total; i += (long)e.nblk * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(e.out)[i] = v;
+  }
+}
+int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s) {
+  if (n <= 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, s, dev_table, n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s) {
   const long total = (long)p.Rp * p.ntaps * p.Cp;
   if (total == 0) return 0;

@@ -81,6 +81,15 @@ struct PackParams {
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
 int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
+// one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch
+struct PackEntry {
+  PackParams p;
+  const float* w;
+  void* out;
+  int bf16;
+  int blk0, nblk;   // blocks [blk0, blk0 + nblk) of the launch belong to this entry
+};
+int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s);
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,

@@ -12,6 +12,7 @@ class vectors, MLP activations) are plain fp32 row-major.
 There is deliberately no CPU path: ops raise if handed a non-HIP tensor.
 """
 import ctypes as C
+import os
 import contextlib
 
 import torch
@@ -197,9 +198,14 @@ def bump_epoch(params):
         _EPOCH[k] = _EPOCH.get(k, 0) + 1
 
 
+def _pack_tag(owner, weight):
+    return (owner._version, weight.data_ptr(), _EPOCH.get(weight.data_ptr(), 0), tuple(weight.shape))
+
+
 def _get_pack(owner, weight, desc, which):
     """``owner`` is the nn.Parameter object: the cache lives ON it, so it dies with the parameter and can
-    never be confused with another tensor that later reuses the same device address."""
+    never be confused with another tensor that later reuses the same device address.  A stale image is
+    re-packed IN PLACE (stable addresses: ``repack_params`` batches all of a network's images in one launch)."""
     cache = getattr(owner, "_mt_packs", None)
     if cache is None:
         cache = {}
@@ -207,17 +213,60 @@ def _get_pack(owner, weight, desc, which):
             owner._mt_packs = cache
         except AttributeError:
             pass
-    key = (which, desc.dtype, desc.transposed, desc.stride, desc.kh, desc.kw)
-    tag = (owner._version, weight.data_ptr(), _EPOCH.get(weight.data_ptr(), 0), tuple(weight.shape))
+    key = (which, desc.dtype, desc.transposed, desc.stride, desc.kh, desc.kw, desc.pad, desc.pad_mode)
+    tag = _pack_tag(owner, weight)
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     lib = L.load()
-    nbytes = lib.mt_conv_pack_bytes(C.byref(desc), which)
-    pack = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=weight.device)
+    nbytes = max(int(lib.mt_conv_pack_bytes(C.byref(desc), which)), 16)
+    if hit is not None and hit[1].numel() == nbytes and hit[1].device == weight.device:
+        pack = hit[1]
+    else:
+        pack = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
     L.check(lib.mt_conv_pack(C.byref(desc), which, _ptr(weight), _ptr(pack), _stream()), "mt_conv_pack")
-    cache[key] = (tag, pack)
+    cache[key] = (tag, pack, L.ConvDesc.from_buffer_copy(desc), which)
     return pack
+
+
+_PACK_TABLES = {}
+
+
+def repack_params(params):
+    """Re-pack every cached weight image of ``params`` in ONE launch (called by FusedAdam after its step: ~100
+    single-image launches of ~6 us each otherwise).  The device-side table is built once per set of addresses."""
+    items = []
+    if os.environ.get("MT_NO_BATCH_PACK") == "1":      # A/B switch (images are then re-packed lazily, one by one)
+        return
+    for p in params:
+        cache = getattr(p, "_mt_packs", None)
+        if not cache or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            continue
+        for key, (tag, pack, desc, which) in cache.items():
+            items.append((p, key, pack, desc, which))
+    if not items:
+        return
+    lib = L.load()
+    sig = tuple((p.data_ptr(), pack.data_ptr(), which, bytes(desc)) for p, _, pack, desc, which in items)
+    tab = _PACK_TABLES.get(sig)
+    if tab is None:
+        n = len(items)
+        descs = (L.ConvDesc * n)(*[it[3] for it in items])
+        whichs = (C.c_int * n)(*[it[4] for it in items])
+        ws = (C.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        packs = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
+        host = C.create_string_buffer(int(lib.mt_conv_pack_multi_table_bytes(n)))
+        ne, nb = C.c_int(), C.c_int()
+        L.check(lib.mt_conv_pack_multi_build(n, descs, whichs, ws, packs, host, C.byref(ne), C.byref(nb)),
+                "mt_conv_pack_multi_build")
+        dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(items[0][0].device)
+        if len(_PACK_TABLES) > 64:
+            _PACK_TABLES.clear()
+        tab = (dev, ne.value, nb.value)
+        _PACK_TABLES[sig] = tab
+    L.check(lib.mt_conv_pack_multi_run(_ptr(tab[0]), tab[1], tab[2], _stream()), "mt_conv_pack_multi_run")
+    for p, key, pack, desc, which in items:
+        p._mt_packs[key] = (_pack_tag(p, p), pack, desc, which)
 
 
 # --------------------------------------------------------------------------------------

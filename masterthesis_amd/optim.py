@@ -85,6 +85,7 @@ class FusedAdam(torch.optim.Adam):
                                        float(g["weight_decay"]), self._step_count_mt,
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mt_adam_multi")
         ops.bump_epoch(self.params())
+        ops.repack_params(self.params())    # all cached weight images of this network, one launch
 
     def state_dict(self):
         for p in self.params():
