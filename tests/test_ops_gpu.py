@@ -64,6 +64,14 @@ CONV_CASES = [
     ("k3s1_tile256_fwd", 4, 32, 128, 128, 256, 3, 1, 1, "reflect", True, "relu"),
     # ... and with Cin = Cout = 256 the zero-padded data gradient does too (H*W*N = 65536 pixels)
     ("k3s1_tile256_zero", 4, 256, 128, 128, 256, 3, 1, 1, "zero", False, None),
+    # K1 shape class: reflect-padded data gradient = interior on the 256x256 ping-pong kernel + border ring
+    ("k3s1_tile256_reflect", 16, 256, 64, 64, 256, 3, 1, 1, "reflect", False, None),
+    # ring path with a 2-pixel border, non-square, and a map too small for the band enumeration of the ring fold
+    ("k3s1_pad2_reflect", 2, 8, 10, 9, 8, 3, 1, 2, "reflect", True, None),
+    ("k3s1_reflect_tiny", 1, 8, 3, 3, 8, 3, 1, 1, "reflect", False, None),
+    ("k5s1_pad2_reflect", 1, 8, 12, 12, 16, 5, 1, 2, "reflect", False, None),   # 65 ring taps > 64: padded-grid path
+    # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
+    ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
 ]
 
 
@@ -358,3 +366,64 @@ def test_adam_multi(hip_device):
         ops.adam_multi(dev, [g.to(hip_device) for g in gs], ms, vs, 1e-3, 0.5, 0.999, 1e-8, 1e-4, step)
     for d, r in zip(dev, ref):
         _close(d, r, torch.float32, what="adam")
+
+
+def test_pack_multi_matches_single(hip_device):
+    """mt_conv_pack_multi_* (one launch for many weight images) writes the same bytes as mt_conv_pack."""
+    import ctypes as C
+    from masterthesis_amd import _lib as L
+    lib = L.load()
+    cases = [  # dtype, transposed, Ci, Co, k, stride, pad, pad_mode, which
+        (L.MT_BF16, 0, 16, 24, 3, 1, 1, L.PAD_REFLECT, L.PACK_FWD),
+        (L.MT_BF16, 0, 16, 24, 3, 1, 1, L.PAD_REFLECT, L.PACK_BWD_DATA),     # ring image (21 taps)
+        (L.MT_BF16, 0, 8, 40, 3, 2, 1, L.PAD_REFLECT, L.PACK_BWD_DATA),      # 4 sub-pixel phase images
+        (L.MT_F32, 1, 24, 8, 3, 2, 1, L.PAD_ZERO, L.PACK_FWD),               # transposed conv, phased
+        (L.MT_F32, 0, 3, 8, 7, 1, 3, L.PAD_REFLECT, L.PACK_BWD_DATA),
+    ]
+    descs, ws, singles, multis, whichs = [], [], [], [], []
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i, (dt, tr, ci, co, k, st, pad, pm, which) in enumerate(cases):
+        d = L.ConvDesc(dt, tr, 2, 16, 16, ci, co, k, k, st, pad, pm, 1 if tr else 0, L.ACT_NONE, 0.0)
+        shape = (ci, co, k, k) if tr else (co, ci, k, k)
+        w = torch.randn(*shape, generator=torch.Generator().manual_seed(i)).to(hip_device)
+        n = int(lib.mt_conv_pack_bytes(C.byref(d), which))
+        a = torch.zeros(n, dtype=torch.uint8, device=hip_device)
+        b = torch.zeros(n, dtype=torch.uint8, device=hip_device)
+        L.check(lib.mt_conv_pack(C.byref(d), which, C.c_void_p(w.data_ptr()), C.c_void_p(a.data_ptr()), stream), "pack")
+        descs.append(d); ws.append(w); singles.append(a); multis.append(b); whichs.append(which)
+    n = len(cases)
+    host = C.create_string_buffer(int(lib.mt_conv_pack_multi_table_bytes(n)))
+    ne, nb = C.c_int(), C.c_int()
+    L.check(lib.mt_conv_pack_multi_build(n, (L.ConvDesc * n)(*descs), (C.c_int * n)(*whichs),
+                                         (C.c_void_p * n)(*[w.data_ptr() for w in ws]),
+                                         (C.c_void_p * n)(*[b.data_ptr() for b in multis]), host, C.byref(ne),
+                                         C.byref(nb)), "build")
+    assert ne.value == 1 + 1 + 4 + 4 + 1
+    dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(hip_device)
+    L.check(lib.mt_conv_pack_multi_run(C.c_void_p(dev.data_ptr()), ne.value, nb.value, stream), "run")
+    torch.cuda.synchronize()
+    for a, b in zip(singles, multis):
+        assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_zero_arena_scope(hip_device):
+    """transient zero buffers: zero at hand-out inside a scope, re-zeroed by the next scope, plain zeros outside."""
+    from masterthesis_amd import hip_ops as ops
+    arena = ops._ZeroArena()
+    t = arena.take((4, 8), hip_device)                      # outside a scope: ordinary allocation
+    assert t.sum().item() == 0
+    arena.begin(hip_device)
+    a = arena.take((3, 5), hip_device)
+    assert a.abs().sum().item() == 0
+    a.fill_(7.0)
+    arena.end()
+    arena.begin(hip_device)
+    b = arena.take((3, 5), hip_device)
+    assert b.data_ptr() == a.data_ptr() and b.abs().sum().item() == 0      # same memory, zero again
+    big = arena.take((1 << 22,), hip_device)                # larger than the arena: falls back, still zero
+    assert big.abs().sum().item() == 0
+    arena.end()
+    arena.begin(hip_device)                                 # the arena grew to the size that was asked for
+    c = arena.take((1 << 22,), hip_device)
+    assert c.abs().sum().item() == 0 and arena.off >= (1 << 22)
+    arena.end()
