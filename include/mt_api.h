@@ -96,8 +96,10 @@ int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, flo
 /* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
 int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,
                   int out, int act, mt_stream_t s);
+/* dx, dw, db may each be NULL.  accumulate != 0: dw and db are ADDED to (gradient accumulation straight into
+ * param.grad), otherwise overwritten. */
 int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
-                  float* db, int n, int in, int out, mt_stream_t s);
+                  float* db, int n, int in, int out, int accumulate, mt_stream_t s);
 
 /* ---- normalisation family (K9, K10, K11): functions.py:17, norm.py:5-33 -------------- */
 /* sums[n][c] += {sum x, sum x^2} over H*W (fp32, [N][Cp][2]); the CALLER zeroes sums (fp32 atomics from

@@ -50,7 +50,7 @@ SIGNATURES = {
     "mt_conv_bwd_weight_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_weight": (_i, [_dp, _p, _p, _p, _p, _p, _z, _i, _p]),
     "mt_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_nc_stats": (_i, [_i, _p, _p, _i, _i, _i, _p]),
     "mt_norm_finalize": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mt_scale_shift_act": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
   if (sl == 0 && i < in) dx[(long)r * in + i] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                     float* __restrict__ dw, float* __restrict__ db, int n, int in, int out) {
+                                     float* __restrict__ dw, float* __restrict__ db, int n, int in, int out,
+                                     int accumulate) {
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= (long)out * in) return;
   const int o = (int)(idx / in), i = (int)(idx % in);
@@ -69,15 +70,15 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* _
     a += g * x[(long)r * in + i];
     bsum += g;
   }
-  dw[idx] = a;
-  if (db && i == 0) db[o] = bsum;
+  dw[idx] = accumulate ? dw[idx] + a : a;
+  if (db && i == 0) db[o] = accumulate ? db[o] + bsum : bsum;
 }
 extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                             int n, int in, int out, mt_stream_t st) {
+                             int n, int in, int out, int accumulate, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   if (n == 0) return 0;
   if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv(in, 64), n), dim3(256), 0, s, w, dy, dx, n, in, out);
-  if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)out * in, 256)), dim3(256), 0, s, x, dy, dw, db, n, in, out);
+  if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)out * in, 256)), dim3(256), 0, s, x, dy, dw, db, n, in, out, accumulate);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -283,6 +283,14 @@ def set_fused_grad_accumulation(on):
     _FUSE_WGRAD_ACC[0] = bool(on)
 
 
+def _fused_grad_target(p):
+    """param.grad if gradients may be accumulated into it in place by the backward kernel, else None"""
+    g = None if p is None else p.grad
+    ok = (_FUSE_WGRAD_ACC[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+          and g.shape == p.shape and g.is_cuda)
+    return g if ok else None
+
+
 def kernel_timer_start(match):
     """Time every conv forward whose descriptor satisfies ``match(desc)`` with HIP events recorded on the
     launch stream."""
@@ -414,13 +422,8 @@ class _Conv(torch.autograd.Function):
             nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
             ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
 
-            def fused_target(p):
-                g = None if p is None else p.grad
-                ok = (_FUSE_WGRAD_ACC[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous()
-                      and g.shape == p.shape and g.is_cuda)
-                return g if ok else None
-            gw = fused_target(ctx.owner) if ctx.needs_input_grad[1] else None
-            gb = fused_target(ctx.bias_owner) if want_b else None
+            gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
+            gb = _fused_grad_target(ctx.bias_owner) if want_b else None
             if gw is not None and (gb is not None or not want_b):
                 # accumulate in place; autograd gets None for both
                 with _oplog("wgrad", desc, (int(want_b),)):
@@ -469,6 +472,7 @@ class _Linear(torch.autograd.Function):
                 "mt_linear_fwd")
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.owners = (weight, bias)
         return y
 
     @staticmethod
@@ -479,9 +483,17 @@ class _Linear(torch.autograd.Function):
         o = w.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_b = need_w and ctx.has_bias
+        gw = _fused_grad_target(ctx.owners[0]) if need_w else None
+        gb = _fused_grad_target(ctx.owners[1]) if want_b else None
+        if need_w and gw is not None and (gb is not None or not want_b):
+            # accumulate straight into param.grad; autograd receives None for both
+            L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(gw), _ptr(gb), n, i, o, 1,
+                                           _stream()), "mt_linear_bwd")
+            return dx, None, None
         dw = torch.empty_like(w) if need_w else None
-        db = torch.empty((o,), dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
-        L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), n, i, o,
+        db = torch.empty((o,), dtype=torch.float32, device=x.device) if want_b else None
+        L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), n, i, o, 0,
                                        _stream()), "mt_linear_bwd")
         return dx, (dw if ctx.needs_input_grad[1] else None), db
 
