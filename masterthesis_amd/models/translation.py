@@ -161,10 +161,16 @@ class TranslationModel(Model):
                                                              (cls_a, cls_a, cls_b, cls_b))
             img_fake = ops.cat_batch((img_ba, img_ab))
             img_random = ops.cat_batch((img_br, img_ar))
+        # the gradient exchange of discriminator1 (side stream) overlaps discriminator2's forward + backward
+        pending = []
         for name, fake in (("discriminator1", img_fake), ("discriminator2", img_random)):
             self.optimizer[name].zero_grad()
             self.backward_discriminator(self.model[name], img, fake, c_org)
-            self._reduce_and_step((name,))
+            opt = self.optimizer[name]
+            pending.append((opt, self.reducer.reduce([opt.flat_grad()])[0]))
+        for opt, h in pending:
+            self.reducer.wait(h)
+            opt.step()
 
     def _dis_outputs(self, netD, x):
         out = netD(x)
