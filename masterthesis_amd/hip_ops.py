@@ -236,8 +236,6 @@ def repack_params(params):
     """Re-pack every cached weight image of ``params`` in ONE launch (called by FusedAdam after its step: ~100
     single-image launches of ~6 us each otherwise).  The device-side table is built once per set of addresses."""
     items = []
-    if os.environ.get("MT_NO_BATCH_PACK") == "1":      # A/B switch (images are then re-packed lazily, one by one)
-        return
     for p in params:
         cache = getattr(p, "_mt_packs", None)
         if not cache or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
