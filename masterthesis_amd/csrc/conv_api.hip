@@ -358,11 +358,32 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
 }
 
 // pixel-split of the weight-gradient reduction: enough (tile, split) blocks to fill 256 CUs x 2
-static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk) {
+// *pipe: the 256x256 ping-pong kernel takes the problem (then the split fills one 8-wave block per CU)
+static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, bool* pipe = nullptr) {
   const int V = vec(d->dtype);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
   const int rows = d->transposed ? Cip : Cop, cols = (d->transposed ? Cop : Cip) * K2;
-  (void)V;
+  if (pipe) *pipe = false;
+  {
+    int Ho, Wo;
+    mt_conv_out_hw(d, &Ho, &Wo);
+    const long ab = (long)M * rows * esz(d->dtype);
+    const long bb = d->transposed ? (long)d->N * Ho * Wo * Cop * esz(d->dtype) : (long)d->N * d->H * d->W * Cip * esz(d->dtype);
+    const int cb = d->transposed ? Cop : Cip;
+    if (mt_wgrad_pipe_ok(d->dtype, rows, cb / V, ab, bb)) {
+      const int tiles = (rows / 256) * (cols / 256);
+      int ns = 256 / tiles;
+      if (ns >= 1 && M / ns >= 512) {
+        int mc = cdiv(cdiv(M, ns), 32) * 32;
+        if (mc <= mt_wgrad_pipe_max_chunk()) {
+          *mchunk = mc;
+          *nsplit = cdiv(M, mc);
+          if (pipe) *pipe = true;
+          return;
+        }
+      }
+    }
+  }
   const int tiles = cdiv(rows, 128) * cdiv(cols, 128);
   // 256 CUs x 2 resident blocks = 512 slots: fill exactly one round (a 1.3-round grid costs two rounds)
   int ns = 512 / tiles;
@@ -442,7 +463,9 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   p.nchunks = p.ntaps * p.cpc;
   const int ncols = p.nchunks * V;
   int nsplit;
-  wgrad_split(d, p.M, &nsplit, &p.mchunk);
+  bool pipe;
+  wgrad_split(d, p.M, &nsplit, &p.mchunk, &pipe);
+  p.ntiles = pipe ? -1 : 0;       // tells mt_launch_wgrad which tiling the split was made for
   if (dw != nullptr) {
     if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
     if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, accumulate, s)) return 2;

@@ -80,6 +80,10 @@ struct PackParams {
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
 int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
+// 256x256 ping-pong variant (wgrad_pipe_kernel.hip)
+bool mt_wgrad_pipe_ok(int dtype, int CaRows, int cpc, long a_bytes, long b_bytes);
+int mt_wgrad_pipe_max_chunk();
+int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
 // one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch
 struct PackEntry {
