@@ -349,6 +349,71 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Few output pixels x few output channels x a long reduction (the discriminators' 4x4 "valid" class head: 32
+// pixels, 2 channels, K = 16 taps x 1024): as a tile GEMM this is ONE block walking 256 k-steps (150 us for 4
+// MFLOP).  Here one block per output pixel streams its K-long gathered row against the <= 8 weight rows.
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void thin_dot_kernel(const IgemmParams p) {
+  constexpr int V = Elem<BF16>::V, SZ = Elem<BF16>::SZ;
+  __shared__ float red[8][256];
+  const IgemmPhase& ph = p.ph[0];
+  const int m = blockIdx.x;
+  const int HoWo = ph.Ho * ph.Wo;
+  const int n = m / HoWo;
+  const int rem = m - n * HoWo;
+  const int ho = rem / ph.Wo, wo = rem - ho * ph.Wo;
+  const int nchunks = ph.ntaps * p.cpc;
+  const u32x4* __restrict__ wbase = reinterpret_cast<const u32x4*>(p.w + ph.w_off);
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) acc[r] = 0.f;
+  for (int q = threadIdx.x; q < nchunks; q += 256) {
+    const int t = q / p.cpc, cq = q - t * p.cpc;
+    int hi = ho * p.is + p.dh[ph.tap0 + t], wi = wo * p.is + p.dw[ph.tap0 + t];
+    bool ok = true;
+    if (p.pad_mode == MT_PAD_REFLECT) {
+      hi = hi < 0 ? -hi : hi;
+      hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
+      wi = wi < 0 ? -wi : wi;
+      wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
+    } else {
+      ok = ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+    }
+    if (!ok) continue;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + ((size_t)(n * p.Hi + hi) * p.Wi + wi) * p.Cib + (size_t)cq * 16);
+    float xf[V];
+    Elem<BF16>::unpack(xv, xf);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (r < p.CoRows) {
+        float wf[V];
+        Elem<BF16>::unpack(wbase[(size_t)r * ph.wrow + q], wf);
+#pragma unroll
+        for (int e = 0; e < V; e++) acc[r] += xf[e] * wf[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) red[r][threadIdx.x] = wave_sum(acc[r]);
+  __syncthreads();
+  if (threadIdx.x < 8 && (int)threadIdx.x < p.Co) {
+    const int co = threadIdx.x;
+    float v = red[co][0] + red[co][64] + red[co][128] + red[co][192];
+    if (p.bias != nullptr && co < p.nbias) v += p.bias[co];
+    v = act_apply(v, p.act, p.slope);
+    const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
+    char* y = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ + (size_t)co * SZ;
+    if constexpr (BF16) *reinterpret_cast<unsigned short*>(y) = f32_to_bf16_bits(v);
+    else *reinterpret_cast<float*>(y) = v;
+  }
+}
+static bool thin_dot_ok(const IgemmParams& p) {
+  return p.nphase == 1 && p.stats == nullptr && p.CoRows <= 8 && p.Co <= 8 && p.ph[0].M <= 1024 &&
+         p.ph[0].ntaps * p.cpc >= 512 && p.os == 1;
+}
+
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(p.nphase >= 1 && p.nphase <= MT_MAX_PHASES, "igemm: bad phase count %d", p.nphase);
   MT_CHECK(p.cpc >= 1, "igemm: bad chunks-per-tap %d", p.cpc);
@@ -362,6 +427,13 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(taps <= MT_MAX_TAPS, "igemm: %d taps > %d", taps, MT_MAX_TAPS);
   IgemmParams q = p;
   q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
+  if (thin_dot_ok(q)) {
+    if (q.ph[0].M == 0) return 0;
+    if (dtype == MT_BF16) hipLaunchKernelGGL((thin_dot_kernel<true>), dim3(q.ph[0].M), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((thin_dot_kernel<false>), dim3(q.ph[0].M), dim3(256), 0, s, q);
+    MT_LAUNCH_CHECK();
+    return 0;
+  }
   return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
 }
 

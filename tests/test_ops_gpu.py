@@ -70,6 +70,9 @@ CONV_CASES = [
     ("k3s1_pad2_reflect", 2, 8, 10, 9, 8, 3, 1, 2, "reflect", True, None),
     ("k3s1_reflect_tiny", 1, 8, 3, 3, 8, 3, 1, 1, "reflect", False, None),
     ("k5s1_pad2_reflect", 1, 8, 12, 12, 16, 5, 1, 2, "reflect", False, None),   # 65 ring taps > 64: padded-grid path
+    # the discriminator's class head: few pixels x 2 channels x K = 16 taps x 1024 -> streaming dot-product kernel
+    ("k4_valid_cls_wide", 4, 1024, 4, 4, 2, 4, 1, 0, "zero", False, None),
+    ("k3_thin_bias_lrelu", 2, 512, 6, 6, 5, 3, 1, 1, "zero", True, "lrelu"),
     # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
     ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
 ]
