@@ -76,6 +76,12 @@ int mt_conv_pack_multi_run(const void* dev_table, int n_entries, int total_block
 /* y = act(conv(x) + bias).  bias may be NULL (length Co, fp32). */
 int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                 void* y, mt_stream_t s);
+/* The same with an optional workspace of mt_conv_fwd_ws_bytes(d) bytes (0 for most shapes): few-pixel / long-K
+ * layers (the discriminators' deep 3x3 / 4x4 stride-2 layers) are then split over the filter taps into fp32
+ * partial slabs (split-K) and summed by a finish kernel -- same result up to fp32 summation order. */
+size_t mt_conv_fwd_ws_bytes(const mt_conv_desc* d);
+int mt_conv_fwd_ex(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
+                   void* y, void* ws, size_t ws_bytes, mt_stream_t s);
 /* Forward with the normalisation statistics of the output fused into the GEMM epilogue:
  * stats [N][Cp][2] = {sum, sum of squares} over H*W per (image, channel) -- the mt_nc_stats() result, so
  * the InstanceNorm/AdaIN/LayerNorm that follows (blocks.py:38-42,158-164) skips its statistics pass.

@@ -44,6 +44,8 @@ SIGNATURES = {
     "mt_conv_pack_multi_build": (_i, [_i, _p, _p, _p, _p, _p, C.POINTER(_i), C.POINTER(_i)]),
     "mt_conv_pack_multi_run": (_i, [_p, _i, _i, _p]),
     "mt_conv_fwd": (_i, [_dp, _p, _p, _p, _p, _p]),
+    "mt_conv_fwd_ws_bytes": (_z, [_dp]),
+    "mt_conv_fwd_ex": (_i, [_dp, _p, _p, _p, _p, _p, _z, _p]),
     "mt_conv_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _p, _p]),
     "mt_conv_bwd_data_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_data": (_i, [_dp, _p, _p, _p, _p, _z, _p]),

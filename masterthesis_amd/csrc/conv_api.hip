@@ -230,9 +230,24 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
 
 // gather-form launch shared by Conv2d fwd and ConvTranspose2d bwd_data.
 //   out[o] = sum_k in[o*stride - pad + k] * W[k]
+// split-K for few-pixel / long-K problems (the discriminators' deep layers: 16-64 tiles walking 144-256 k-steps
+// each): the filter taps are divided over up to 16 launch phases that write fp32 partial slabs, a finish kernel
+// sums them and applies bias + activation.  Returns the number of splits (1 = no split).
+static int gather_splitk(int M, int Cout_p, int Cin_p, int ntaps, int V) {
+  const int WT = Cout_p > 64 ? 128 : (Cout_p > 32 ? 64 : (Cout_p > 16 ? 32 : 16));
+  const int tiles = cdiv(M, 128) * cdiv(Cout_p, WT);
+  const int nk = cdiv((long)ntaps * (Cin_p / V), 8);
+  if (tiles > 96 || nk < 48 || ntaps < 2) return 1;
+  int ks = 512 / tiles;
+  if (ks > ntaps) ks = ntaps;
+  if (ks > MT_MAX_PHASES) ks = MT_MAX_PHASES;
+  while (ks > 1 && nk / ks < 8) ks--;      // keep at least 8 k-steps per split
+  return ks < 2 ? 1 : ks;
+}
+
 static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
                        const float* bias, int nbias, void* out, int Hg, int Wg, int Cout_p, int pad_mode, int act,
-                       hipStream_t s, float* stats = nullptr) {
+                       hipStream_t s, float* stats = nullptr, void* ws = nullptr, size_t ws_bytes = 0) {
   const int sz = esz(d->dtype), V = vec(d->dtype);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -252,11 +267,41 @@ static int gather_form(const mt_conv_desc* d, const void* in, int Hin, int Win, 
       p.dh[a * d->kw + b] = (short)(a - d->pad);
       p.dw[a * d->kw + b] = (short)(b - d->pad);
     }
+  const int ks = (stats == nullptr && ws != nullptr) ? gather_splitk(q.M, Cout_p, Cin_p, q.ntaps, V) : 1;
+  const size_t slab = (size_t)q.M * Cout_p * sizeof(float);
+  if (ks > 1 && ws_bytes >= slab * ks && slab * ks < 0xf0000000ull) {
+    const IgemmPhase full = q;
+    const int base = full.ntaps / ks, rem = full.ntaps % ks;
+    int t0 = 0;
+    for (int i = 0; i < ks; i++) {
+      IgemmPhase& f = p.ph[i];
+      f = full;
+      f.tap0 = t0; f.ntaps = base + (i < rem ? 1 : 0);
+      f.w_off = (unsigned)((size_t)t0 * Cin_p * sz); f.w_bytes = full.w_bytes - f.w_off;
+      f.y_off = (unsigned)(slab * i);
+      t0 += f.ntaps;
+    }
+    p.nphase = ks;
+    p.y = (char*)ws; p.raw = 1; p.bias = nullptr; p.nbias = 0; p.act = MT_ACT_NONE;
+    if (mt_launch_igemm(d->dtype, p, s)) return 2;
+    return mt_launch_splitk_finish(d->dtype, (const float*)ws, ks, (long)q.M * Cout_p, bias, nbias, Cout_p, out, act,
+                                   d->slope, s);
+  }
   return mt_launch_igemm(d->dtype, p, s);
 }
 
-extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
-                           mt_stream_t st) {
+extern "C" size_t mt_conv_fwd_ws_bytes(const mt_conv_desc* d) {
+  if (d->transposed || mt_pointwise_small(d)) return 0;
+  int Ho, Wo;
+  if (mt_conv_out_hw(d, &Ho, &Wo)) return 0;
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  const int M = d->N * Ho * Wo;
+  const int ks = gather_splitk(M, Cop, Cip, d->kh * d->kw, vec(d->dtype));
+  return ks > 1 ? (size_t)ks * M * Cop * sizeof(float) : 0;
+}
+
+extern "C" int mt_conv_fwd_ex(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
+                              void* ws, size_t ws_bytes, mt_stream_t st) {
   if (check_desc(d)) return 1;
   hipStream_t s = (hipStream_t)st;
   int Ho, Wo;
@@ -264,8 +309,14 @@ extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pac
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
   if (mt_pointwise_small(d)) return mt_pw_fwd(d, x, pack_fwd, bias, y, (long)d->N * d->H * d->W, s);
   if (!d->transposed)
-    return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s);
+    return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, nullptr, ws,
+                       ws_bytes);
   return scatter_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad, d->act, s);
+}
+
+extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias, void* y,
+                           mt_stream_t st) {
+  return mt_conv_fwd_ex(d, x, pack_fwd, bias, y, nullptr, 0, st);
 }
 
 extern "C" int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);

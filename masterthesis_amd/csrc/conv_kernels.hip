@@ -251,8 +251,20 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
       const int wo = rem - ho * ph_Wo;
       const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
       if ((unsigned)oh < (unsigned)p.Hout && (unsigned)ow < (unsigned)p.Wout)
-        yp[b] = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
+        yp[b] = p.y + ph.y_off + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * (p.raw ? 4 : SZ);
     }
+  }
+  if (p.raw) {
+    // split-K partial: the fp32 accumulators go to this phase's slab; bias / activation are applied by the finish
+#pragma unroll
+    for (int a = 0; a < FC; a++) {
+      const int co = wt * WT + wcI * WC + a * 16 + fg * 4;
+      if (co >= p.Co) continue;
+#pragma unroll
+      for (int b = 0; b < FP; b++)
+        if (yp[b] != nullptr) *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = acc[a][b];
+    }
+    return;
   }
   // fused InstanceNorm statistics (p.stats != null): all PT pixels of the block lie in ONE image (host
   // guarantees Ho*Wo % 256 == 0).  Sum over the wave's pixel fragments in registers, over the 16 pixel lanes
@@ -328,7 +340,7 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   // (the ping-pong kernel steps whole 4-chunk k-steps inside a tap and marks zero lanes with offsets >= 2 GiB)
   const bool pipe_ok = p.cpc % 4 == 0 && p.ph[0].ntaps <= 25 /* MT_PIPE_MAX_TAPS */ && p.x_bytes < 0x7f000000u &&
                        p.ph[0].w_bytes < 0x7f000000u;
-  if (p.nphase == 1 && p.CoRows % 256 == 0 && pipe_ok) {
+  if (p.nphase == 1 && !p.raw && p.CoRows % 256 == 0 && pipe_ok) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
     if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
   }
@@ -410,8 +422,46 @@ __global__ __launch_bounds__(256) void thin_dot_kernel(const IgemmParams p) {
   }
 }
 static bool thin_dot_ok(const IgemmParams& p) {
-  return p.nphase == 1 && p.stats == nullptr && p.CoRows <= 8 && p.Co <= 8 && p.ph[0].M <= 1024 &&
+  return p.nphase == 1 && !p.raw && p.stats == nullptr && p.CoRows <= 8 && p.Co <= 8 && p.ph[0].M <= 1024 &&
          p.ph[0].ntaps * p.cpc >= 512 && p.os == 1;
+}
+
+template <bool BF16>
+__global__ void splitk_finish_kernel(const f32x4* __restrict__ slabs, int nsplit, long total4, long slab4,
+                                     const float* __restrict__ bias, int nbias, int Cp, void* __restrict__ y, int act,
+                                     float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 a = slabs[i];
+    for (int k = 1; k < nsplit; k++) a += slabs[i + (long)k * slab4];
+    const int c = (int)((i * 4) % Cp);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float b = (bias != nullptr && c + j < nbias) ? bias[c + j] : 0.f;
+      v[j] = act_apply(a[j] + b, act, slope);
+    }
+    if constexpr (BF16) {
+      u32x2 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+      reinterpret_cast<u32x2*>(y)[i] = o;
+    } else {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+  }
+}
+int mt_launch_splitk_finish(int dtype, const float* slabs, int nsplit, long total, const float* bias, int nbias, int Cp,
+                            void* y, int act, float slope, hipStream_t s) {
+  if (total == 0) return 0;
+  const long total4 = total / 4;     // Cp is a multiple of 8
+  const int blocks = (int)min((long)4096, (total4 + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((splitk_finish_kernel<true>), dim3(blocks), dim3(256), 0, s, (const f32x4*)slabs, nsplit, total4,
+                       total4, bias, nbias, Cp, y, act, slope);
+  else
+    hipLaunchKernelGGL((splitk_finish_kernel<false>), dim3(blocks), dim3(256), 0, s, (const f32x4*)slabs, nsplit, total4,
+                       total4, bias, nbias, Cp, y, act, slope);
+  MT_LAUNCH_CHECK();
+  return 0;
 }
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {

@@ -21,6 +21,7 @@ struct IgemmPhase {
   int Ho, Wo, M;      // GEMM pixel grid of the phase, M = N*Ho*Wo
   int oh0, ow0;       // output pixel = (ho*os + oh0, wo*os + ow0)
   int blk0, nblk;     // filled by the launcher for the chosen tile geometry
+  unsigned y_off;     // byte offset of this phase's output tensor from IgemmParams::y (split-K partial slabs)
 };
 
 struct IgemmParams {
@@ -46,6 +47,8 @@ struct IgemmParams {
   int pad_mode;
   int act;
   float slope;
+  int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements
+                      // whatever the storage type); mt_launch_splitk_finish sums the slabs
   short dh[MT_MAX_TAPS];
   short dw[MT_MAX_TAPS];
 };
@@ -79,6 +82,9 @@ struct PackParams {
 };
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
+// y[i] = act(sum_s slabs[s][i] + bias[i % Cp])  (i over `total` NHWC elements, fp32 slabs, output in `dtype`)
+int mt_launch_splitk_finish(int dtype, const float* slabs, int nsplit, long total, const float* bias, int nbias,
+                            int Cp, void* y, int act, float slope, hipStream_t s);
 int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
 // 256x256 ping-pong variant (wgrad_pipe_kernel.hip)
 bool mt_wgrad_pipe_ok(int dtype, int CaRows, int cpc, long a_bytes, long b_bytes);

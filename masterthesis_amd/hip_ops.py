@@ -378,8 +378,10 @@ class _Conv(torch.autograd.Function):
                 L.check(lib.mt_conv_fwd_stats(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(sums),
                                               _stream()), "mt_conv_fwd_stats")
             else:
-                L.check(lib.mt_conv_fwd(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _stream()),
-                        "mt_conv_fwd")
+                nws = int(lib.mt_conv_fwd_ws_bytes(C.byref(desc)))      # > 0 only for split-K shapes
+                ws = torch.empty((nws,), dtype=torch.uint8, device=x.device) if nws else None
+                L.check(lib.mt_conv_fwd_ex(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(ws), nws,
+                                           _stream()), "mt_conv_fwd_ex")
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()

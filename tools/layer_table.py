@@ -27,8 +27,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--crop_size", type=int, default=256)
+    ap.add_argument("--ms_dis", action="store_true")
     a = ap.parse_args()
-    o = argparse.Namespace(precision="bf16", num_domains=2, batch_size=a.batch_size, crop_size=a.crop_size, ms_dis=False)
+    o = argparse.Namespace(precision="bf16", num_domains=2, batch_size=a.batch_size, crop_size=a.crop_size, ms_dis=a.ms_dis)
     from masterthesis_amd import hip_ops as ops, models
     from masterthesis_amd.dataset import SyntheticDataset
     dev = torch.device("cuda", 0)
