@@ -190,9 +190,38 @@ extern "C" int mt_conv_pack_multi_run(const void* dev_table, int n_entries, int 
 // scatter-form launches shared by Conv2d bwd_data and ConvTranspose2d fwd.
 //   out[o] = sum_k in[(o + e - k)/stride] * W[k]   over k with (o + e - k) % stride == 0
 // in: [N][Hin][Win][Cin_p], out: [N][Hd][Wd][Cout_p]
+// split-K plan of a scatter-form launch (see gather_splitk): number of tap splits per sub-pixel phase (1 = none)
+static int scatter_splitk(const mt_conv_desc* d, int Hd, int Wd, int Cin_p, int Cout_p, int e) {
+  const int st = d->stride, V = vec(d->dtype);
+  const int WT = Cout_p > 64 ? 128 : (Cout_p > 32 ? 64 : (Cout_p > 16 ? 32 : 16));
+  int tiles = 0, maxtaps = 0, np = 0;
+  for (int ph = 0; ph < st; ph++)
+    for (int pw = 0; pw < st; pw++) {
+      short kh[MT_MAX_TAPS], kw[MT_MAX_TAPS];
+      const int nt = phase_taps(d, ph, pw, kh, kw);
+      const int o0h = posmod(ph - e, st), o0w = posmod(pw - e, st);
+      const int Hg = o0h < Hd ? (Hd - o0h + st - 1) / st : 0;
+      const int Wg = o0w < Wd ? (Wd - o0w + st - 1) / st : 0;
+      const int M = d->N * Hg * Wg;
+      if (M == 0) continue;
+      np++;
+      tiles += cdiv(M, 128) * cdiv(Cout_p, WT);
+      maxtaps = nt > maxtaps ? nt : maxtaps;
+    }
+  if (np == 0 || tiles > 96 || maxtaps < 2) return 1;
+  const int nk = cdiv((long)maxtaps * (Cin_p / V), 8);
+  if (nk < 32) return 1;
+  int ks = 512 / tiles;
+  if (ks > maxtaps) ks = maxtaps;
+  if (ks > MT_MAX_PHASES / np) ks = MT_MAX_PHASES / np;
+  while (ks > 1 && nk / ks < 8) ks--;
+  return ks < 2 ? 1 : ks;
+}
+
+// split_ws: optional fp32 workspace of scatter_splitk(...) * N*Hd*Wd*Cout_p floats for the split-K partial slabs
 static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
                         const float* bias, int nbias, void* out, int Hd, int Wd, int Cout_p, int e, int act,
-                        hipStream_t s) {
+                        hipStream_t s, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
   const int sz = esz(d->dtype), V = vec(d->dtype), st = d->stride;
   MT_CHECK(st * st <= MT_MAX_PHASES, "conv: stride %d has too many phases", st);
   IgemmParams p;
@@ -225,6 +254,34 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
       if (q.M > 0) p.nphase++;   // an empty phase (no output pixels) is dropped; a phase without taps writes zeros
     }
   if (p.nphase == 0) return 0;
+  const int ks = split_ws != nullptr ? scatter_splitk(d, Hd, Wd, Cin_p, Cout_p, e) : 1;
+  const size_t slab = (size_t)d->N * Hd * Wd * Cout_p * sizeof(float);
+  if (ks > 1 && split_ws_bytes >= slab * ks && slab * ks < 0xf0000000ull && p.nphase * ks <= MT_MAX_PHASES) {
+    // every sub-pixel phase is split over its taps; split i of every phase writes slab i (a split without taps
+    // writes zeros there, so the finish kernel can sum all slabs everywhere)
+    IgemmPhase orig[MT_MAX_PHASES];
+    const int np = p.nphase;
+    for (int i = 0; i < np; i++) orig[i] = p.ph[i];
+    p.nphase = 0;
+    for (int j = 0; j < np; j++) {
+      const int base = orig[j].ntaps / ks, rem = orig[j].ntaps % ks;
+      int t0 = 0;
+      for (int i = 0; i < ks; i++) {
+        IgemmPhase& f = p.ph[p.nphase++];
+        f = orig[j];
+        f.ntaps = base + (i < rem ? 1 : 0);
+        f.tap0 = orig[j].tap0 + t0;
+        const size_t sub = (size_t)t0 * Cin_p * sz;
+        f.w_off = orig[j].w_off + (unsigned)sub; f.w_bytes = orig[j].w_bytes - (unsigned)sub;
+        f.y_off = (unsigned)(slab * i);
+        t0 += f.ntaps;
+      }
+    }
+    p.y = (char*)split_ws; p.raw = 1; p.bias = nullptr; p.nbias = 0; p.act = MT_ACT_NONE;
+    if (mt_launch_igemm(d->dtype, p, s)) return 2;
+    return mt_launch_splitk_finish(d->dtype, (const float*)split_ws, ks, (long)d->N * Hd * Wd * Cout_p, bias, nbias,
+                                   Cout_p, out, act, d->slope, s);
+  }
   return mt_launch_igemm(d->dtype, p, s);
 }
 
@@ -342,9 +399,23 @@ extern "C" int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const voi
   return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, stats);
 }
 
-extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {
+// workspace of the data gradient: [padded gradient map (reflect padding only)] [split-K partial slabs (if any)]
+static size_t bwd_data_padded_bytes(const mt_conv_desc* d) {
   if (d->transposed || d->pad_mode != MT_PAD_REFLECT || d->pad == 0) return 0;
-  return (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * mt_padc(d->Ci) * esz(d->dtype);
+  const size_t b = (size_t)d->N * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * mt_padc(d->Ci) * esz(d->dtype);
+  return (b + 255) & ~(size_t)255;
+}
+static size_t bwd_data_split_bytes(const mt_conv_desc* d) {
+  if (d->transposed || mt_pointwise_small(d)) return 0;
+  RingTaps rt;
+  if (ring_taps(d, &rt)) return 0;
+  const int P = (d->pad_mode == MT_PAD_REFLECT) ? d->pad : 0;
+  const int Hd = d->H + 2 * P, Wd = d->W + 2 * P, Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
+  const int ks = scatter_splitk(d, Hd, Wd, Cop, Cip, P ? 0 : d->pad);
+  return ks > 1 ? (size_t)ks * d->N * Hd * Wd * Cip * sizeof(float) : 0;
+}
+extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {
+  return bwd_data_padded_bytes(d) + bwd_data_split_bytes(d);
 }
 
 extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, void* ws,
@@ -358,9 +429,13 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   if (d->transposed)
     return gather_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, MT_PAD_ZERO, MT_ACT_NONE, s);
   const int P = (d->pad_mode == MT_PAD_REFLECT) ? d->pad : 0;
+  const size_t padded_b = bwd_data_padded_bytes(d), split_b = bwd_data_split_bytes(d);
+  const bool have_ws = ws != nullptr && ws_bytes >= padded_b + split_b;
+  void* split_ws = (have_ws && split_b) ? (char*)ws + padded_b : nullptr;
   if (P == 0)
-    return scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, d->pad, MT_ACT_NONE, s);
-  MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_data_ws_bytes(d), "conv_bwd_data: workspace too small");
+    return scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, d->pad, MT_ACT_NONE, s, split_ws,
+                        split_b);
+  MT_CHECK(ws != nullptr && ws_bytes >= padded_b, "conv_bwd_data: workspace too small");
   RingTaps rt;
   if (ring_taps(d, &rt)) {
     const int sz = esz(d->dtype), V = vec(d->dtype);
@@ -403,7 +478,8 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
     // (3) fold the ring onto the border band
     return mt_launch_ring_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
   }
-  if (scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s))
+  if (scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s,
+                   split_ws, split_b))
     return 2;
   return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
 }

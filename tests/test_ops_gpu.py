@@ -76,6 +76,10 @@ CONV_CASES = [
     # few pixels x long K (the discriminators' deep layers): forward split over the filter taps (split-K)
     ("k3s2_deep_splitk", 4, 512, 8, 8, 256, 3, 2, 1, "reflect", True, "lrelu"),
     ("k4s2_msd_splitk", 2, 256, 8, 8, 128, 4, 2, 1, "zero", False, "lrelu"),
+    # ... and the data gradient of such layers (scatter form: every sub-pixel phase split over its taps; the
+    # reflect-padded one writes the padded map first)
+    ("k3s2_dgrad_splitk", 2, 64, 8, 8, 1024, 3, 2, 1, "reflect", True, None),
+    ("k4s2_dgrad_splitk_zero", 2, 32, 8, 8, 1024, 4, 2, 1, "zero", False, "lrelu"),
     # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
     ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
 ]
