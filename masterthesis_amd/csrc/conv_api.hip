@@ -208,7 +208,7 @@ static int scatter_splitk(const mt_conv_desc* d, int Hd, int Wd, int Cin_p, int 
       tiles += cdiv(M, 128) * cdiv(Cout_p, WT);
       maxtaps = nt > maxtaps ? nt : maxtaps;
     }
-  if (np == 0 || tiles > 96 || maxtaps < 2) return 1;
+  if (np == 0 || tiles > 128 || maxtaps < 2) return 1;
   const int nk = cdiv((long)maxtaps * (Cin_p / V), 8);
   if (nk < 32) return 1;
   int ks = 512 / tiles;
@@ -294,7 +294,7 @@ static int gather_splitk(int M, int Cout_p, int Cin_p, int ntaps, int V) {
   const int WT = Cout_p > 64 ? 128 : (Cout_p > 32 ? 64 : (Cout_p > 16 ? 32 : 16));
   const int tiles = cdiv(M, 128) * cdiv(Cout_p, WT);
   const int nk = cdiv((long)ntaps * (Cin_p / V), 8);
-  if (tiles > 96 || nk < 48 || ntaps < 2) return 1;
+  if (tiles > 128 || nk < 48 || ntaps < 2) return 1;
   int ks = 512 / tiles;
   if (ks > ntaps) ks = ntaps;
   if (ks > MT_MAX_PHASES) ks = MT_MAX_PHASES;
