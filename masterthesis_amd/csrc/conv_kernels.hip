@@ -344,6 +344,17 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
     if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
   }
+  // 128 couts x 512 pixels ping-pong tiles for the Cout = 128 layers (any number of phases, <= 9 taps each)
+  if (WT == 128 && PT == 128 && !p.raw && p.stats == nullptr && p.CoRows % 128 == 0 && p.cpc % 4 == 0 &&
+      p.x_bytes < 0x7f000000u) {
+    bool ok = true;
+    int n512 = 0;
+    for (int i = 0; i < p.nphase; i++) {
+      ok = ok && p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
+      n512 += cdiv(p.ph[i].M, 512) * (p.CoRows / 128);
+    }
+    if (ok && n512 >= 224 && (n512 % 256 == 0 || n512 >= 768)) { PT = 512; WT = 128; }
+  }
   int total = 0;
   for (int i = 0; i < p.nphase; i++) {
     p.ph[i].blk0 = total;
@@ -351,8 +362,8 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
     total += p.ph[i].nblk;
   }
   if (total == 0) return 0;
-  // 256x256 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
-  if (WT == 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  // 256x256 and 128x512 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
+  if (PT >= 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 32) hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(total), dim3(256), 0, s, p);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 constexpr int MT_PIPE_MAX_TAPS = 25;   // rows of the per-tile gather-offset table (+1 all-zero row)
 
-template <bool BF16, int WT, int PT, int NT, int NS>
+template <bool BF16, int WT, int PT, int NT, int NS, int MAXTAPS>
 __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   constexpr int NW = NT / 64;
   constexpr int WC = 128, WP = 64;                  // wave tile: 128 output channels x 64 pixels
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   constexpr int WR = WT;                            // weight rows per stage
   constexpr int PPS = NXL + NWL;                    // copies per wave per stage
   constexpr int STAGE = (WR + PT) * 4;              // u32x4 per stage (4 chunks per 64-byte row)
-  constexpr int TROWS = MT_PIPE_MAX_TAPS + 1;
+  constexpr int TROWS = MAXTAPS + 1;               // rows of the gather-offset table (+1 all-zero row)
   static_assert(NW == 8 && NW == (PT / WP) * (WT / WC), "two wave groups of four, one wave of each per SIMD");
   static_assert(NXL * NW * 16 == PT && NWL * NW * 16 == WT, "tiles are a whole number of copies per wave");
   static_assert(NS >= 3 && (NS - 2) * PPS <= 63, "vmcnt range");
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   // straddles a filter tap and the tap index is wave-uniform.
   const int rsub = lane >> 2;
   const int c = (lane & 3) ^ ((rsub >> 1) & 3);
-  unsigned wo32[2], xo32[2];
-  int prow[2];                  // this lane's pixel rows of the tile (one per copy instruction)
-  static_assert(NWL <= 2 && NXL <= 2, "literal-sized arrays (hipcc drops the host stub for a dependent-size lambda capture)");
+  unsigned wo32[2], xo32[4];
+  int prow[4];                  // this lane's pixel rows of the tile (one per copy instruction)
+  static_assert(NWL <= 2 && NXL <= 4, "literal-sized arrays (hipcc drops the host stub for a dependent-size lambda capture)");
 #pragma unroll
   for (int i = 0; i < NXL; i++) prow[i] = 16 * (wvu + NW * i) + rsub;
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
                                                0);
   };
   // table entries of the stage after the one just issued (scalar tap / chunk bookkeeping, two LDS reads)
-  unsigned tq[2];
+  unsigned tq[4];
   auto next_lookup = [&]() {
     cqb += 4;
     const bool wrap = cqb >= p.cpc;
@@ -340,12 +340,16 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   MT_STAMP(3);
 }
 
-// geometry choice shared with the launcher in conv_kernels.hip
+// geometry choice shared with the launcher in conv_kernels.hip:
+//   WT = 256: 256 couts x 256 pixels, 4-stage ring, <= 25 taps
+//   WT = 128: 128 couts x 512 pixels (8 waves along the pixels), 3-stage ring, <= 9 taps -- the Cout = 128 layers
 template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s) {
-  if (WT == 256) hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 256, 256, 512, 4>), dim3(total), dim3(512), 0, s, p);
-  else { mt_set_error("igemm_pipe: no instantiation for WT=%d", WT); return 1; }
-  (void)PT;
+  if (WT == 256 && PT == 256)
+    hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 256, 256, 512, 4, MT_PIPE_MAX_TAPS>), dim3(total), dim3(512), 0, s, p);
+  else if (WT == 128 && PT == 512)
+    hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 128, 512, 512, 3, 9>), dim3(total), dim3(512), 0, s, p);
+  else { mt_set_error("igemm_pipe: no instantiation for %d x %d", WT, PT); return 1; }
   MT_LAUNCH_CHECK();
   return 0;
 }

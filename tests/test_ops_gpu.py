@@ -80,6 +80,10 @@ CONV_CASES = [
     # reflect-padded one writes the padded map first)
     ("k3s2_dgrad_splitk", 2, 64, 8, 8, 1024, 3, 2, 1, "reflect", True, None),
     ("k4s2_dgrad_splitk_zero", 2, 32, 8, 8, 1024, 4, 2, 1, "zero", False, "lrelu"),
+    # Cout = 128 on a big map: 128 x 512 ping-pong tiles
+    # (no activation: at 16.8 M outputs an fp32 ReLU mask flips on a few within-rounding-of-zero elements)
+    ("k3s1_pipe512", 8, 64, 128, 128, 128, 3, 1, 1, "reflect", True, None),
+    ("k3s2_pipe512", 8, 32, 256, 256, 128, 3, 2, 1, "reflect", True, None),
     # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
     ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
 ]
@@ -134,6 +138,7 @@ CONVT_CASES = [
     ("k4s2p1", 1, 8, 6, 6, 8, 4, 2, 1, 0, False, None),
     ("k1s1_tanh_rgb64", 2, 64, 24, 24, 3, 1, 1, 0, 0, False, "tanh"),     # the decoder's to-RGB layer
     ("k1s1_bias_16", 1, 16, 9, 7, 5, 1, 1, 0, 0, True, None),
+    ("k3s2_pipe512", 8, 64, 64, 64, 128, 3, 2, 1, 1, True, None),     # 4 sub-pixel phases on 128 x 512 ping-pong tiles
 ]
 
 
