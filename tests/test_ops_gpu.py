@@ -84,6 +84,8 @@ CONV_CASES = [
     # (no activation: at 16.8 M outputs an fp32 ReLU mask flips on a few within-rounding-of-zero elements)
     ("k3s1_pipe512", 8, 64, 128, 128, 128, 3, 1, 1, "reflect", True, None),
     ("k3s2_pipe512", 8, 32, 256, 256, 128, 3, 2, 1, "reflect", True, None),
+    ("k3s1_co64_big", 8, 64, 128, 128, 64, 3, 1, 1, "reflect", True, None),      # Cout <= 64 on a big map
+    ("k3s1_co40_big", 8, 32, 128, 128, 40, 3, 1, 1, "zero", False, None),        # ... with a partial channel tile
     # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
     ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
 ]
@@ -139,6 +141,7 @@ CONVT_CASES = [
     ("k1s1_tanh_rgb64", 2, 64, 24, 24, 3, 1, 1, 0, 0, False, "tanh"),     # the decoder's to-RGB layer
     ("k1s1_bias_16", 1, 16, 9, 7, 5, 1, 1, 0, 0, True, None),
     ("k3s2_pipe512", 8, 64, 64, 64, 128, 3, 2, 1, 1, True, None),     # 4 sub-pixel phases on 128 x 512 ping-pong tiles
+    ("k3s2_co64_big", 8, 128, 64, 64, 64, 3, 2, 1, 1, True, None),    # the decoder's last up-conv shape class
 ]
 
 
