@@ -174,6 +174,15 @@ int mt_bce_const_fwd(int dtype, const void* x, float t, float* loss, size_t npix
 /* dx = gscale[0] * (sigmoid(x) - t) / (npix*C) on logical channels, 0 on pad. */
 int mt_bce_const_bwd(int dtype, const void* x, float t, const float* gscale, void* dx,
                      size_t npix, int C, int Cp, mt_stream_t s);
+/* The other GANLoss modes, same conventions as mt_bce_const_* (loss.py:44-61; adain_model.py:209-210, 293-295):
+ * LSGAN mean (x-t)^2; HINGE_D mean relu(1-x) for t=1 / mean relu(1+x) for t=0; NEG_MEAN -mean x for t=1 / mean x. */
+#define MT_GAN_LSGAN 1
+#define MT_GAN_HINGE_D 2
+#define MT_GAN_NEG_MEAN 3
+int mt_gan_const_fwd(int dtype, int mode, const void* x, float t, float* loss, size_t npix, int C, int Cp,
+                     mt_stream_t s);
+int mt_gan_const_bwd(int dtype, int mode, const void* x, float t, const float* gscale, void* dx, size_t npix,
+                     int C, int Cp, mt_stream_t s);
 /* mean BCE-with-logits of fp32 x[n] against fp32 targets t[n]. */
 int mt_bce_target_fwd(const float* x, const float* t, float* loss, size_t n, mt_stream_t s);
 int mt_bce_target_bwd(const float* x, const float* t, const float* gscale, float* dx, size_t n,

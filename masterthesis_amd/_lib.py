@@ -15,6 +15,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PACK_FWD, PACK_BWD_DATA = 0, 1
 NORM_INSTANCE, NORM_ADAIN, NORM_LAYER = 0, 1, 2
+GAN_LSGAN, GAN_HINGE_D, GAN_NEG_MEAN = 1, 2, 3
 
 
 class ConvDesc(C.Structure):
@@ -75,6 +76,8 @@ SIGNATURES = {
     "mt_slice_channels": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_bce_const_fwd": (_i, [_i, _p, _f, _p, _z, _i, _i, _p]),
     "mt_bce_const_bwd": (_i, [_i, _p, _f, _p, _p, _z, _i, _i, _p]),
+    "mt_gan_const_fwd": (_i, [_i, _i, _p, _f, _p, _z, _i, _i, _p]),
+    "mt_gan_const_bwd": (_i, [_i, _i, _p, _f, _p, _p, _z, _i, _i, _p]),
     "mt_bce_target_fwd": (_i, [_p, _p, _p, _z, _p]),
     "mt_bce_target_bwd": (_i, [_p, _p, _p, _p, _z, _p]),
     "mt_l1_fwd": (_i, [_i, _p, _p, _p, _z, _z, _p]),

@@ -80,6 +80,83 @@ extern "C" int mt_bce_const_bwd(int dtype, const void* x, float t, const float* 
   return 0;
 }
 
+// ---- the other GANLoss modes on an NHWC-padded map (loss.py:44-61, adain_model.py:209-210,293-295,367-369) ----
+//   MT_GAN_LSGAN      mean (x - t)^2                 nn.MSELoss vs ones / zeros
+//   MT_GAN_HINGE_D    mean relu(1 - x) (t = 1)  /  mean relu(1 + x) (t = 0)     discriminator hinge terms
+//   MT_GAN_NEG_MEAN   -mean x (t = 1)  /  mean x (t = 0)                        generator hinge term, wgangp
+__device__ __forceinline__ float gan_term(int mode, float v, float t) {
+  switch (mode) {
+    case MT_GAN_LSGAN: return (v - t) * (v - t);
+    case MT_GAN_HINGE_D: { const float z = t > 0.5f ? 1.f - v : 1.f + v; return z > 0.f ? z : 0.f; }
+    default: return t > 0.5f ? -v : v;
+  }
+}
+__device__ __forceinline__ float gan_term_grad(int mode, float v, float t) {
+  switch (mode) {
+    case MT_GAN_LSGAN: return 2.f * (v - t);
+    case MT_GAN_HINGE_D: { const float z = t > 0.5f ? 1.f - v : 1.f + v; return z > 0.f ? (t > 0.5f ? -1.f : 1.f) : 0.f; }
+    default: return t > 0.5f ? -1.f : 1.f;
+  }
+}
+template <bool BF16>
+__global__ void gan_const_fwd_kernel(int mode, const void* __restrict__ x, float t, float* __restrict__ loss, long npix,
+                                     int C, int Cp, float inv_count) {
+  const long total = npix * C;
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / C;
+    const int c = (int)(i % C);
+    float v;
+    if constexpr (BF16) v = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(x)[px * Cp + c]);
+    else v = reinterpret_cast<const float*>(x)[px * Cp + c];
+    a += gan_term(mode, v, t);
+  }
+  wave_atomic_add(loss, a * inv_count);
+}
+template <bool BF16>
+__global__ void gan_const_bwd_kernel(int mode, const void* __restrict__ x, float t, const float* __restrict__ gscale,
+                                     void* __restrict__ dx, long npix, int C, int Cp, float inv_count) {
+  const long total = npix * Cp;
+  const float gs = gscale[0] * inv_count;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    float g = 0.f;
+    if (c < C) {
+      float v;
+      if constexpr (BF16) v = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(x)[i]);
+      else v = reinterpret_cast<const float*>(x)[i];
+      g = gan_term_grad(mode, v, t) * gs;
+    }
+    if constexpr (BF16) reinterpret_cast<unsigned short*>(dx)[i] = f32_to_bf16_bits(g);
+    else reinterpret_cast<float*>(dx)[i] = g;
+  }
+}
+extern "C" int mt_gan_const_fwd(int dtype, int mode, const void* x, float t, float* loss, size_t npix, int C, int Cp,
+                                mt_stream_t st) {
+  MT_CHECK(mode == MT_GAN_LSGAN || mode == MT_GAN_HINGE_D || mode == MT_GAN_NEG_MEAN, "gan_const: bad mode %d", mode);
+  hipStream_t s = (hipStream_t)st;
+  if (zero_scalar(loss, s)) return 2;
+  const long total = (long)npix * C;
+  if (total == 0) return 0;
+  const float inv = 1.f / (float)total;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((gan_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv);
+  else hipLaunchKernelGGL((gan_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_gan_const_bwd(int dtype, int mode, const void* x, float t, const float* gscale, void* dx, size_t npix,
+                                int C, int Cp, mt_stream_t st) {
+  MT_CHECK(mode == MT_GAN_LSGAN || mode == MT_GAN_HINGE_D || mode == MT_GAN_NEG_MEAN, "gan_const: bad mode %d", mode);
+  hipStream_t s = (hipStream_t)st;
+  const long total = (long)npix * Cp;
+  if (total == 0) return 0;
+  const float inv = 1.f / (float)((long)npix * C);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((gan_const_bwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, gscale, dx, (long)npix, C, Cp, inv);
+  else hipLaunchKernelGGL((gan_const_bwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, gscale, dx, (long)npix, C, Cp, inv);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- BCE vs per-element target, fp32 vectors ---------------------------------------------------
 __global__ void bce_target_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                       float* __restrict__ loss, long n, float inv) {

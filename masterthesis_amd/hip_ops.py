@@ -814,6 +814,43 @@ class _BceConst(torch.autograd.Function):
         return dx, None
 
 
+class _GanConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode, t):
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().mt_gan_const_fwd(_mt(x.dtype), mode, _ptr(x), t, _ptr(loss), N * H * W, Cc, padc(Cc),
+                                          _stream()), "mt_gan_const_fwd")
+        ctx.mode, ctx.t = mode, t
+        ctx.save_for_backward(x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dx = new_act(N, Cc, H, W, x.dtype, x.device)
+        L.check(L.load().mt_gan_const_bwd(_mt(x.dtype), ctx.mode, _ptr(x), ctx.t, _ptr(_gs(g)), _ptr(dx), N * H * W, Cc,
+                                          padc(Cc), _stream()), "mt_gan_const_bwd")
+        return dx, None, None
+
+
+def mse_const(x, target_is_real):
+    """nn.MSELoss()(x, ones/zeros expanded) -- GANLoss 'lsgan' (loss.py:44-45, 58-63)"""
+    return _GanConst.apply(x, L.GAN_LSGAN, 1.0 if target_is_real else 0.0)
+
+
+def hinge_dis(x, is_real):
+    """relu(1 - x).mean() for real logits, relu(1 + x).mean() for fake ones (adain_model.py:209-210)"""
+    return _GanConst.apply(x, L.GAN_HINGE_D, 1.0 if is_real else 0.0)
+
+
+def neg_mean(x):
+    """-x.mean(): the generator's hinge term (adain_model.py:293-295)"""
+    return _GanConst.apply(x, L.GAN_NEG_MEAN, 1.0)
+
+
 def bce_logits_const(x, target_is_real):
     """nn.BCEWithLogitsLoss()(x, ones/zeros expanded) -- GANLoss 'vanilla' (loss.py:58-63)"""
     return _BceConst.apply(x, 1.0 if target_is_real else 0.0)

@@ -6,15 +6,31 @@ from ... import hip_ops as ops
 
 
 class GANLoss(nn.Module):
+    """'vanilla' (BCE with logits) and 'lsgan' (MSE) against constant ones / zeros.  With 'hinge' the reference
+    never calls this module (its ``self.loss`` is None, loss.py:46-47): the hinge terms are written out in the model
+    (adain_model.py:209-210, 293-295) -- ``hinge_dis`` / ``hinge_gen`` below are those expressions."""
+
     def __init__(self, loss="vanilla"):
         super().__init__()
-        if loss != "vanilla":
-            raise NotImplementedError(f"gan_mode '{loss}' has no HIP kernel in this build (only 'vanilla', the "
-                                      "reference default, is on the north-star path)")
+        if loss not in ("vanilla", "lsgan", "hinge"):
+            raise NotImplementedError(f"gan_mode '{loss}' is not implemented in this build ('bce' needs sigmoid outputs, "
+                                      "'wgangp' has no gradient penalty in the reference either)")
         self.loss_type = loss
 
     def forward(self, inp, trg_is_real, is_dis=None):
-        return ops.bce_logits_const(inp, bool(trg_is_real))
+        if self.loss_type == "vanilla":
+            return ops.bce_logits_const(inp, bool(trg_is_real))
+        if self.loss_type == "lsgan":
+            return ops.mse_const(inp, bool(trg_is_real))
+        raise TypeError("'NoneType' object is not callable")      # what the reference raises for 'hinge' here
+
+    @staticmethod
+    def hinge_dis(pred_real, pred_fake):
+        return ops.hinge_dis(pred_real, True) + ops.hinge_dis(pred_fake, False)
+
+    @staticmethod
+    def hinge_gen(pred_fake):
+        return ops.neg_mean(pred_fake)
 
 
 class ClassificationLoss(nn.Module):

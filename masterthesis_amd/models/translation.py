@@ -182,10 +182,14 @@ class TranslationModel(Model):
         per-sample independent layers => identical outputs, half the launches, twice the pixels per GEMM)."""
         n = fake.shape[0]
         loss_d_adv, loss_d_cls = 0, 0
+        hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:209; ms_dis goes via gan_loss)
         for pred, cls in self._dis_outputs(netD, ops.cat_batch((fake.detach(), real))):
             pf, pr = torch.split(pred, n, dim=0)
             cr = cls[n:]
-            loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
+            if hinge:
+                loss_d_adv = loss_d_adv + self.gan_loss.hinge_dis(pr, pf)
+            else:
+                loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
             loss_d_cls = loss_d_cls + self.classification_loss(cr, c_org)
         loss_d = loss_d_adv + self.args.lambda_cls * loss_d_cls
         loss_d.backward()
@@ -207,9 +211,10 @@ class TranslationModel(Model):
 
     def _generator_adv(self, netD, fake, c_org):
         adv, cls = 0, 0
+        hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:293-295, 367-369)
         with ops.frozen(netD):
             for pf, cf in self._dis_outputs(netD, fake):
-                adv = adv + self.gan_loss(pf, 1)
+                adv = adv + (self.gan_loss.hinge_gen(pf) if hinge else self.gan_loss(pf, 1))
                 cls = cls + self.classification_loss(cf, c_org)
         return adv, cls * self.args.lambda_cls_G
 

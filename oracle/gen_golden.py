@@ -233,12 +233,27 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     torch.set_num_threads(4)
-    nets_case()
-    step_case("adain_step_d2", "AdaINModel", steps=2, seed=0, num_domains=2, batch_size=1)
+    only = set(sys.argv[1:])          # optional: names of the fixtures to (re)generate
+
+    def want(name):
+        return not only or name in only
+    if want("nets_forward"):
+        nets_case()
+    if want("adain_step_d2"):
+        step_case("adain_step_d2", "AdaINModel", steps=2, seed=0, num_domains=2, batch_size=1)
     # dim 4: channel counts that are not multiples of 8 (exercises the channel padding)
-    step_case("adain_step_d4_b2", "AdaINModel", steps=1, seed=1, num_domains=4, batch_size=2, dim=4)
-    step_case("base_step_concat_reparam", "BaseModel", steps=1, seed=2, num_domains=2, batch_size=1, dim=4,
-              concat=True, reparam=True)
+    if want("adain_step_d4_b2"):
+        step_case("adain_step_d4_b2", "AdaINModel", steps=1, seed=1, num_domains=4, batch_size=2, dim=4)
+    if want("base_step_concat_reparam"):
+        step_case("base_step_concat_reparam", "BaseModel", steps=1, seed=2, num_domains=2, batch_size=1, dim=4,
+                  concat=True, reparam=True)
+    # optional GAN objectives: --gan_mode lsgan / hinge
+    if want("adain_step_lsgan"):
+        step_case("adain_step_lsgan", "AdaINModel", steps=1, seed=4, num_domains=2, batch_size=1, dim=4,
+                  gan_mode="lsgan")
+    if want("adain_step_hinge"):
+        step_case("adain_step_hinge", "AdaINModel", steps=1, seed=5, num_domains=2, batch_size=1, dim=4,
+                  gan_mode="hinge")
     return 0
 
 

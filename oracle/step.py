@@ -82,6 +82,11 @@ def gan_loss(mode, x, real):
     raise NotImplementedError(mode)
 
 
+def hinge_dis(pr, pf):
+    # adain_model.py:209-210
+    return F.relu(1.0 - pr).mean() + F.relu(1.0 + pf).mean()
+
+
 class OracleModel:
     """Functional twin of the reference ``Model``: ``P[net][key]`` leaf tensors + one Adam each."""
 
@@ -139,8 +144,9 @@ class OracleModel:
         a = self.args
         self.opt[which].zero_grad()
         adv, cls = 0, 0
+        hinge = "hinge" in a.gan_mode and not a.ms_dis
         for (pf, _), (pr, cr) in zip(self.D(which, fake.detach()), self.D(which, real)):
-            adv = adv + gan_loss(a.gan_mode, pf, False) + gan_loss(a.gan_mode, pr, True)
+            adv = adv + (hinge_dis(pr, pf) if hinge else gan_loss(a.gan_mode, pf, False) + gan_loss(a.gan_mode, pr, True))
             cls = cls + F.binary_cross_entropy_with_logits(cr, c_org)
         total = adv + a.lambda_cls * cls
         total.backward()
@@ -164,8 +170,9 @@ class OracleModel:
     def _g_adv(self, which, fake, c_org):                   # adain_model.py:278-301
         a = self.args
         adv, cls = 0, 0
+        hinge = "hinge" in a.gan_mode and not a.ms_dis                  # adain_model.py:293-295, 367-369
         for pf, cf in self.D(which, fake):
-            adv = adv + gan_loss(a.gan_mode, pf, True)
+            adv = adv + (-pf.mean() if hinge else gan_loss(a.gan_mode, pf, True))
             cls = cls + F.binary_cross_entropy_with_logits(cf, c_org)
         return adv, cls * a.lambda_cls_G
 

@@ -327,6 +327,19 @@ def test_losses(dtype, hip_device):
         (l * 3).backward()
         _close(l, lr, dtype, what="bce_const")
         _close(xd.grad, xr.grad, dtype, what="bce_const dx")
+    # the other GANLoss modes: lsgan (MSE vs ones / zeros) and the hinge terms written out in the reference model
+    for what, ref_fn, dev_fn in (
+            ("lsgan_real", lambda v: F.mse_loss(v, torch.ones_like(v)), lambda v: ops.mse_const(v, True)),
+            ("lsgan_fake", lambda v: F.mse_loss(v, torch.zeros_like(v)), lambda v: ops.mse_const(v, False)),
+            ("hinge_real", lambda v: F.relu(1.0 - v).mean(), lambda v: ops.hinge_dis(v, True)),
+            ("hinge_fake", lambda v: F.relu(1.0 + v).mean(), lambda v: ops.hinge_dis(v, False)),
+            ("hinge_gen", lambda v: -v.mean(), lambda v: ops.neg_mean(v))):
+        xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+        lr, l = ref_fn(xr), dev_fn(xd)
+        (lr * 3).backward()
+        (l * 3).backward()
+        _close(l, lr, dtype, what=what)
+        _close(xd.grad, xr.grad, dtype, what=what + " dx")
     p, t = _rnd(6, 4, seed=2), torch.eye(4)[[0, 1, 2, 3, 1, 2]]
     pr, pd = p.clone().requires_grad_(), p.to(hip_device).requires_grad_()
     lr, l = F.binary_cross_entropy_with_logits(pr, t), ops.bce_logits(pd, t.to(hip_device))
