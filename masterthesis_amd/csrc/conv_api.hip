@@ -499,9 +499,11 @@ static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, 
     const int cb = d->transposed ? Cop : Cip;
     if (mt_wgrad_pipe_ok(d->dtype, rows, cb / V, ab, bb)) {
       const int tiles = (rows / 256) * (cols / 256);
-      int ns = 256 / tiles;
-      if (ns >= 1 && M / ns >= 512) {
-        int mc = cdiv(cdiv(M, ns), 32) * 32;
+      // one round of 256 blocks; two or four rounds when a split would not fit the per-block pixel-offset table
+      for (int rounds = 1; rounds <= 4; rounds *= 2) {
+        const int ns = rounds * 256 / tiles;
+        if (ns < 1 || M / ns < 512) break;
+        const int mc = cdiv(cdiv(M, ns), 32) * 32;
         if (mc <= mt_wgrad_pipe_max_chunk()) {
           *mchunk = mc;
           *nsplit = cdiv(M, mc);

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [
     ("K1_res3x3_256", False, 16, 256, 64, 64, 256, 3, 1, 1, "reflect", 0),
     ("K1_res3x3_256_N32", False, 32, 256, 64, 64, 256, 3, 1, 1, "reflect", 0),
+    ("K1_res3x3_256_N64", False, 64, 256, 64, 64, 256, 3, 1, 1, "reflect", 0),     # config 3 (B=16): two-round wgrad
     ("stem7x7_3_64", False, 16, 3, 256, 256, 64, 7, 1, 3, "reflect", 0),
     ("down3x3s2_64_128", False, 16, 64, 256, 256, 128, 3, 2, 1, "reflect", 0),
     ("down3x3s2_128_256", False, 16, 128, 128, 128, 256, 3, 2, 1, "reflect", 0),
