@@ -364,6 +364,12 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   if (total == 0) return 0;
   // 256x256 and 128x512 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
   if (PT >= 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  // launches that do not fill the chip (latency-bound k loops): the 4-wave ring variant
+  {
+    bool ok = (WT == 128 || WT == 64) && !p.raw && p.cpc % 4 == 0 && p.x_bytes < 0x7f000000u && total <= 256;
+    for (int i = 0; i < p.nphase && ok; i++) ok = p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
+    if (ok) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  }
   if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 32) hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(total), dim3(256), 0, s, p);

@@ -41,18 +41,20 @@ constexpr int MT_PIPE_MAX_TAPS = 25;   // rows of the per-tile gather-offset tab
 template <bool BF16, int WT, int PT, int NT, int NS, int MAXTAPS>
 __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   constexpr int NW = NT / 64;
-  constexpr int WC = 128, WP = 64;                  // wave tile: 128 output channels x 64 pixels
+  // wave tile: 8 waves 128 couts x 64 pixels; 4 waves (NT = 256, latency-bound small launches) up to 64 x 64
+  constexpr int WC = NW == 8 ? 128 : 64;
+  constexpr int WP = (NW == 8 || WT >= 128) ? 64 : 32;
   constexpr int NWP = PT / WP;
   constexpr int FC = WC / 16, FP = WP / 16;
   constexpr int SZ = BF16 ? 2 : 4;
   constexpr int NXL = PT / 16 / NW;                 // pixel-tile copies per wave per stage
-  constexpr int NWL = WT / 16 / NW;                 // weight-tile copies per wave per stage
-  constexpr int WR = WT;                            // weight rows per stage
+  constexpr int NWL = (WT / 16 + NW - 1) / NW;      // weight-tile copies per wave per stage (incl. dummy rows)
+  constexpr int WR = NWL * NW * 16;                 // weight rows per stage (>= WT)
   constexpr int PPS = NXL + NWL;                    // copies per wave per stage
   constexpr int STAGE = (WR + PT) * 4;              // u32x4 per stage (4 chunks per 64-byte row)
   constexpr int TROWS = MAXTAPS + 1;               // rows of the gather-offset table (+1 all-zero row)
-  static_assert(NW == 8 && NW == (PT / WP) * (WT / WC), "two wave groups of four, one wave of each per SIMD");
-  static_assert(NXL * NW * 16 == PT && NWL * NW * 16 == WT, "tiles are a whole number of copies per wave");
+  static_assert(NW == (PT / WP) * (WT / WC), "wave grid must cover the block tile");
+  static_assert(NXL * NW * 16 == PT, "the pixel tile is a whole number of copies per wave");
   static_assert(NS >= 3 && (NS - 2) * PPS <= 63, "vmcnt range");
   static_assert(FC % 2 == 0, "the epilogue stores fragment pairs");
   static_assert((NS * STAGE * 16 + TROWS * PT * 4) <= 160 * 1024, "LDS budget");
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
     // channel held by that row: within each 32-row fragment pair, row (a&1)*16 + r <- channel (r>>2)*8 + (a&1)*4 + (r&3)
     const int rl = (rs & ~31) | ((((rs & 15) >> 2) << 3) | (((rs >> 4) & 1) << 2) | (rs & 3));
     const int row = wt * WT + rl;
-    wo32[i] = row < p.CoRows ? ((unsigned)row * (unsigned)ph.wrow + (unsigned)c) * 16u : OOB;
+    wo32[i] = (rs < WT && row < p.CoRows) ? ((unsigned)row * (unsigned)ph.wrow + (unsigned)c) * 16u : OOB;
   }
   int tap_s = 0, cqb = 0;       // wave-uniform: filter tap and first chunk inside it of the NEXT stage to issue
 
@@ -145,17 +147,20 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   // the PPS copy instructions of one stage into ring slot `slot`
   // (no K-tail check on the weight side: there the pixel operand is zero, and reading into the next pack row
   // or past the end -- range-checked -> 0 -- only multiplies finite weights by 0)
-  auto issue_stage = [&](int slot) {
+  auto issue_piece = [&](int slot, int j) {
     char* base = lds0 + slot * (STAGE * 16);
-#pragma unroll
-    for (int i = 0; i < NWL; i++) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * i) * 1024), 16, wo32[i], 0, 0, 0);
-      wo32[i] += 64u;
-    }
-#pragma unroll
-    for (int i = 0; i < NXL; i++)
+    if (j < NWL) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j], 0, 0, 0);
+      wo32[j] += 64u;
+    } else {
+      const int i = j - NWL;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(base + WR * 64 + (wvu + NW * i) * 1024), 16, xo32[i], 0, 0,
                                                0);
+    }
+  };
+  auto issue_stage = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < PPS; j++) issue_piece(slot, j);
   };
   // table entries of the stage after the one just issued (scalar tap / chunk bookkeeping, two LDS reads)
   unsigned tq[4];
@@ -193,6 +198,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   wait_vmcnt<(NS - 2) * PPS>();
   MT_STAMP(1);
 
+  int slot = 0;   // ring slot of stage ks
+  if constexpr (NW == 8) {
   // ---- ping-pong main loop: waves 0-3 and 4-7 (one of each per SIMD) alternate between a MEMORY phase
   // (LDS-DMA of stage ks+NS-1, fragment reads of stage ks) and a COMPUTE phase (32 back-to-back MFMAs), half
   // a k-step apart, so each SIMD's matrix pipe always has one wave feeding it while the other one waits on
@@ -202,7 +209,6 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   //   landing:    at the end of memory phase ks a wave waits until all but its newest (NS-2)*PPS copies are
   //               done, i.e. its part of stage ks+1 is in LDS before the barrier in front of anyone's reads.
   const int grp = wvu >> 2;
-  int slot = 0;   // ring slot of stage ks
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave's copies of stage 0 have landed
   asm volatile("" ::: "memory");
@@ -253,6 +259,46 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  }
+  } else {
+    // ---- 4-wave geometries: one raw barrier per k-step, the copies of stage ks+NS-1 issued one at a time
+    // between the MFMA groups.  Used for launches that do not fill the chip (<= 1 block per CU): there the
+    // 2-stage kernel exposes a full memory latency per k-step, the counted-vmcnt ring hides it.
+    for (int ks = 0; ks < nk; ks++) {
+      wait_vmcnt<(NS - 2) * PPS>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int fill = slot - 1;                 // slot of stage ks-1 == slot of stage ks+NS-1
+      fill = fill < 0 ? NS - 1 : fill;
+      u32x4 wf[FC], xf[FP];
+      {
+        const u32x4* sWs = &smem[slot * STAGE];
+        const u32x4* sXs = sWs + WR * 4;
+#pragma unroll
+        for (int a = 0; a < FC; a++) {
+          const int row = wcI * WC + a * 16 + fr;
+          wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
+        }
+#pragma unroll
+        for (int b = 0; b < FP; b++) {
+          const int row = wpI * WP + b * 16 + fr;
+          xf[b] = sXs[row * 4 + (fg ^ ((row >> 1) & 3))];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < FC; a++) {
+#pragma unroll
+        for (int j = (a * PPS) / FC; j < ((a + 1) * PPS) / FC; j++) issue_piece(fill, j);
+        if (a == FC - 1) next_lookup();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      next_offsets();
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
   }
   MT_STAMP(2);
   wait_vmcnt<0>();     // the trailing (all-zero) copies must have landed before LDS is reused / the wave exits
@@ -343,12 +389,17 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
 // geometry choice shared with the launcher in conv_kernels.hip:
 //   WT = 256: 256 couts x 256 pixels, 4-stage ring, <= 25 taps
 //   WT = 128: 128 couts x 512 pixels (8 waves along the pixels), 3-stage ring, <= 9 taps -- the Cout = 128 layers
+//   128 x 128 / 64 x 128 with 4 waves: the ring without ping-pong, for launches of at most one block per CU
 template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s) {
   if (WT == 256 && PT == 256)
     hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 256, 256, 512, 4, MT_PIPE_MAX_TAPS>), dim3(total), dim3(512), 0, s, p);
   else if (WT == 128 && PT == 512)
     hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 128, 512, 512, 3, 9>), dim3(total), dim3(512), 0, s, p);
+  else if (WT == 128 && PT == 128)
+    hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 128, 128, 256, 4, 9>), dim3(total), dim3(256), 0, s, p);
+  else if (WT == 64 && PT == 128)
+    hipLaunchKernelGGL((igemm_pipe_kernel<BF16, 64, 128, 256, 4, 9>), dim3(total), dim3(256), 0, s, p);
   else { mt_set_error("igemm_pipe: no instantiation for %d x %d", WT, PT); return 1; }
   MT_LAUNCH_CHECK();
   return 0;
