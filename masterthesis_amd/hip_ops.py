@@ -851,6 +851,54 @@ def neg_mean(x):
     return _GanConst.apply(x, L.GAN_NEG_MEAN, 1.0)
 
 
+class _SubMean(torch.autograd.Function):
+    """y = x - mean(other) on logit maps (the relativistic-average GAN terms, adain_model.py:206-208): composed of
+    the existing kernels -- mean via mt_gan_const_fwd(NEG_MEAN), the shift via mt_scale_shift_act, and in the
+    backward pass d(other) = -sum(g)/count via mt_gan_const_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, other):
+        lib = L.load()
+        x, other = canon(x), canon(other)
+        N, Cc, H, W = x.shape
+        No, Co, Ho, Wo = other.shape
+        Cp = padc(Cc)
+        m = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(lib.mt_gan_const_fwd(_mt(other.dtype), L.GAN_NEG_MEAN, _ptr(other), 0.0, _ptr(m), No * Ho * Wo, Co,
+                                     padc(Co), _stream()), "mt_gan_const_fwd")            # t = 0: +mean(other)
+        scale = torch.ones((N, Cp), dtype=torch.float32, device=x.device)
+        shift = (-m).reshape(1, 1).expand(N, Cp).contiguous()
+        y = new_act(N, Cc, H, W, x.dtype, x.device)
+        L.check(lib.mt_scale_shift_act(_mt(x.dtype), _ptr(x), _ptr(scale), _ptr(shift), None, _ptr(y), N, H * W, Cp,
+                                       L.ACT_NONE, 0.0, _stream()), "mt_scale_shift_act")
+        ctx.save_for_backward(other)
+        ctx.xshape = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        (other,) = ctx.saved_tensors
+        g = canon(g)
+        N, Cc, H, W = ctx.xshape
+        No, Co, Ho, Wo = other.shape
+        dother = None
+        if ctx.needs_input_grad[1]:
+            mg = torch.empty((), dtype=torch.float32, device=g.device)
+            L.check(lib.mt_gan_const_fwd(_mt(g.dtype), L.GAN_NEG_MEAN, _ptr(g), 0.0, _ptr(mg), N * H * W, Cc, padc(Cc),
+                                         _stream()), "mt_gan_const_fwd")
+            gs = (mg * (-float(N * H * W * Cc))).reshape(1).contiguous()            # -sum(g)
+            dother = new_act(No, Co, Ho, Wo, other.dtype, other.device)
+            L.check(lib.mt_gan_const_bwd(_mt(other.dtype), L.GAN_NEG_MEAN, _ptr(other), 0.0, _ptr(gs), _ptr(dother),
+                                         No * Ho * Wo, Co, padc(Co), _stream()), "mt_gan_const_bwd")
+        return (g if ctx.needs_input_grad[0] else None), dother
+
+
+def sub_mean(x, other):
+    """x - torch.mean(other)"""
+    return _SubMean.apply(x, other)
+
+
 def bce_logits_const(x, target_is_real):
     """nn.BCEWithLogitsLoss()(x, ones/zeros expanded) -- GANLoss 'vanilla' (loss.py:58-63)"""
     return _BceConst.apply(x, 1.0 if target_is_real else 0.0)

@@ -61,8 +61,6 @@ class TranslationModel(Model):
         self.gan_loss = losses.GANLoss(args.gan_mode)
         self.classification_loss = losses.ClassificationLoss()
         self.l1_loss = losses.L1Loss()
-        if getattr(args, "use_ragan", False):
-            raise NotImplementedError("--use_ragan is not implemented in this build (SURVEY.md 8f-4)")
         if args.vgg_loss is not None:
             raise NotImplementedError("--vgg_loss needs downloaded VGG weights; out of scope")
         self.print_loss = ["g_adv", "g_cls", "l1_cc_rec"]
@@ -183,10 +181,14 @@ class TranslationModel(Model):
         n = fake.shape[0]
         loss_d_adv, loss_d_cls = 0, 0
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:209; ms_dis goes via gan_loss)
+        ragan = getattr(self.args, "use_ragan", False) and not self.args.ms_dis      # (adain_model.py:206-208)
         for pred, cls in self._dis_outputs(netD, ops.cat_batch((fake.detach(), real))):
             pf, pr = torch.split(pred, n, dim=0)
             cr = cls[n:]
-            if hinge:
+            if ragan:
+                loss_d_adv = loss_d_adv + (self.gan_loss(ops.sub_mean(pr, pf), 1) +
+                                           self.gan_loss(ops.sub_mean(pf, pr), 0)) / 2
+            elif hinge:
                 loss_d_adv = loss_d_adv + self.gan_loss.hinge_dis(pr, pf)
             else:
                 loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
@@ -209,9 +211,16 @@ class TranslationModel(Model):
         self.backward_decoder_random(img, c_org)
         self._reduce_and_step(("content_encoder", "decoder"))
 
-    def _generator_adv(self, netD, fake, c_org):
+    def _generator_adv(self, netD, fake, c_org, netD_real=None):
         adv, cls = 0, 0
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:293-295, 367-369)
+        if getattr(self.args, "use_ragan", False) and not self.args.ms_dis:
+            # relativistic average (286-292, 360-366): real logits from netD_real on the input images
+            with ops.frozen(netD, netD_real):
+                pr, _ = netD_real(self.img)
+                pf, cf = netD(fake)
+                adv = (self.gan_loss(ops.sub_mean(pr, pf), 0) + self.gan_loss(ops.sub_mean(pf, pr), 1)) / 2
+                return adv, self.classification_loss(cf, c_org) * self.args.lambda_cls_G
         with ops.frozen(netD):
             for pf, cf in self._dis_outputs(netD, fake):
                 adv = adv + (self.gan_loss.hinge_gen(pf) if hinge else self.gan_loss(pf, 1))
@@ -239,7 +248,8 @@ class TranslationModel(Model):
         if a.use_dis_content:
             with ops.frozen(self.model.content_discriminator):
                 loss_g_content = self.backward_content_discriminator(z_c)
-        loss_g_adv, loss_g_cls = self._generator_adv(self.model.discriminator1, img_fake, c_org)
+        loss_g_adv, loss_g_cls = self._generator_adv(self.model.discriminator1, img_fake, c_org,
+                                                     netD_real=self.model.discriminator1)
         loss_g_self = self.l1_loss(img, img_self) * a.lambda_rec
         loss_g_cc = self.l1_loss(img, img_recon) * a.lambda_rec
         loss_kl_zc = ops.l2_mean(z_c) * 0.01
@@ -265,8 +275,10 @@ class TranslationModel(Model):
         img_br, img_ar = self._translate((z_cb, z_ca), (z_sr, z_sr), (cls_a, cls_b))        # one 2B-image decoder call
         img_random = ops.cat_batch((img_br, img_ar))
         # with --ms_dis the reference scores the random translations with discriminator1 (352-353)
-        netD = self.model.discriminator1 if a.ms_dis else self.model.discriminator2
-        loss_g_adv2, loss_g_cls2 = self._generator_adv(netD, img_random, c_org)
+        # ... and with --use_ragan the fake logits come from discriminator1, the real ones from discriminator2 (360-362)
+        ragan = getattr(a, "use_ragan", False) and not a.ms_dis
+        netD = self.model.discriminator1 if (a.ms_dis or ragan) else self.model.discriminator2
+        loss_g_adv2, loss_g_cls2 = self._generator_adv(netD, img_random, c_org, netD_real=self.model.discriminator2)
         if self.reparam:
             with ops.frozen(self.model.style_encoder):      # Es is not stepped in this phase (235-239)
                 _, mu2, _ = self._encode_style(img_random, c_org)

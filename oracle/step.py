@@ -68,7 +68,7 @@ def default_args(**kw):
     a = dict(model="AdaINModel", input_dim=3, dim=64, num_domains=2, latent_dim=8, batch_size=1, crop_size=256,
              ms_dis=False, num_scales=3, use_dis_content=False, concat=False, reparam=False,
              lr=1e-4, wd=1e-4, beta1=0.5, beta2=0.999, n_iter_decay=600000, d_iter=3,
-             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla")
+             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla", use_ragan=False)
     a.update(kw)
     return SimpleNamespace(**a)
 
@@ -145,8 +145,14 @@ class OracleModel:
         self.opt[which].zero_grad()
         adv, cls = 0, 0
         hinge = "hinge" in a.gan_mode and not a.ms_dis
+        ragan = a.use_ragan and not a.ms_dis                            # adain_model.py:206-208
         for (pf, _), (pr, cr) in zip(self.D(which, fake.detach()), self.D(which, real)):
-            adv = adv + (hinge_dis(pr, pf) if hinge else gan_loss(a.gan_mode, pf, False) + gan_loss(a.gan_mode, pr, True))
+            if ragan:
+                adv = adv + (gan_loss(a.gan_mode, pr - torch.mean(pf), True) +
+                             gan_loss(a.gan_mode, pf - torch.mean(pr), False)) / 2
+            else:
+                adv = adv + (hinge_dis(pr, pf) if hinge else
+                             gan_loss(a.gan_mode, pf, False) + gan_loss(a.gan_mode, pr, True))
             cls = cls + F.binary_cross_entropy_with_logits(cr, c_org)
         total = adv + a.lambda_cls * cls
         total.backward()
@@ -167,10 +173,15 @@ class OracleModel:
         self._d_phase("discriminator1", img, torch.cat((img_ba, img_ab)), c)
         self._d_phase("discriminator2", img, torch.cat((img_br, img_ar)), c)
 
-    def _g_adv(self, which, fake, c_org):                   # adain_model.py:278-301
+    def _g_adv(self, which, fake, c_org, real_from=None):   # adain_model.py:278-301, 352-373
         a = self.args
         adv, cls = 0, 0
         hinge = "hinge" in a.gan_mode and not a.ms_dis                  # adain_model.py:293-295, 367-369
+        if a.use_ragan and not a.ms_dis:                                # 286-292, 360-366 (relativistic average)
+            (pr, _), = self.D(real_from, self.img)
+            (pf, cf), = self.D(which, fake)
+            adv = (gan_loss(a.gan_mode, pr - torch.mean(pf), False) + gan_loss(a.gan_mode, pf - torch.mean(pr), True)) / 2
+            return adv, F.binary_cross_entropy_with_logits(cf, c_org) * a.lambda_cls_G
         for pf, cf in self.D(which, fake):
             adv = adv + (-pf.mean() if hinge else gan_loss(a.gan_mode, pf, True))
             cls = cls + F.binary_cross_entropy_with_logits(cf, c_org)
@@ -198,7 +209,7 @@ class OracleModel:
         if a.use_dis_content:
             pred = nets.content_discriminator(self.P["content_discriminator"], z_c)
             g_content = F.binary_cross_entropy_with_logits(pred, 1 - c)
-        g_adv, g_cls = self._g_adv("discriminator1", img_fake, c)
+        g_adv, g_cls = self._g_adv("discriminator1", img_fake, c, real_from="discriminator1")
         l_self = F.l1_loss(img, img_self) * a.lambda_rec
         l_cc = F.l1_loss(img, img_recon) * a.lambda_rec
         kl_zc = torch.mean(z_c ** 2) * 0.01
@@ -222,7 +233,10 @@ class OracleModel:
         z_sr = rng.z((B, a.latent_dim))
         img_random = torch.cat((self.Dec(z_cb, z_sr, cls_a), self.Dec(z_ca, z_sr, cls_b)))
         # --ms_dis scores with discriminator1 here (reference quirk, lines 352-353)
-        adv, cls = self._g_adv("discriminator1" if a.ms_dis else "discriminator2", img_random, c)
+        # ... and with --use_ragan the fake logits come from discriminator1, the real ones from discriminator2 (360-362)
+        ragan = a.use_ragan and not a.ms_dis
+        adv, cls = self._g_adv("discriminator1" if (a.ms_dis or ragan) else "discriminator2", img_random, c,
+                               real_from="discriminator2")
         if self.reparam:
             _, mu2, _ = self.Es(img_random, c, rng)
             m_a, m_b = torch.split(mu2, B)

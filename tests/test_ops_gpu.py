@@ -340,6 +340,17 @@ def test_losses(dtype, hip_device):
         (l * 3).backward()
         _close(l, lr, dtype, what=what)
         _close(xd.grad, xr.grad, dtype, what=what + " dx")
+    # relativistic-average term: x - mean(other), gradient to both
+    o = _rnd(4, 1, 6, 6, seed=11)
+    xr, orr = x.clone().requires_grad_(), o.clone().requires_grad_()
+    xd, od = x.to(hip_device).requires_grad_(), o.to(hip_device).requires_grad_()
+    lr = F.binary_cross_entropy_with_logits(xr - torch.mean(orr), torch.ones_like(xr))
+    l = ops.bce_logits_const(ops.sub_mean(xd, od), True)
+    lr.backward()
+    l.backward()
+    _close(l, lr, dtype, what="sub_mean loss")
+    _close(xd.grad, xr.grad, dtype, what="sub_mean dx")
+    _close(od.grad, orr.grad, dtype, what="sub_mean dother")
     p, t = _rnd(6, 4, seed=2), torch.eye(4)[[0, 1, 2, 3, 1, 2]]
     pr, pd = p.clone().requires_grad_(), p.to(hip_device).requires_grad_()
     lr, l = F.binary_cross_entropy_with_logits(pr, t), ops.bce_logits(pd, t.to(hip_device))
