@@ -147,6 +147,10 @@ int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t 
                           uint64_t offset, mt_stream_t s);
 int mt_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
+/* nn.Upsample(scale_factor=2, mode='nearest') (blocks.py:75, --up_type nearest).  H, W: size of the UPSAMPLED map.
+ * fwd: src [N][H/2][W/2][Cp] -> dst [N][H][W][Cp]; bwd: src = d(upsampled) [N][H][W][Cp] -> dst [N][H/2][W/2][Cp]. */
+int mt_upsample2_fwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s);
+int mt_upsample2_bwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s);
 /* AvgPool2d(3, stride 2, pad 1, count_include_pad=False) (networks.py:447) */
 int mt_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);

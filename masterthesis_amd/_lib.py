@@ -66,6 +66,8 @@ SIGNATURES = {
     "mt_gaussian_noise_add": (_i, [_i, _p, _p, _z, _u64, _u64, _p]),
     "mt_avgpool2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_upsample2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_upsample2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool3s2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool3s2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_gap_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),

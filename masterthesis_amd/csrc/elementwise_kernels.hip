@@ -144,9 +144,11 @@ extern "C" int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n
 
 // ---- pooling ------------------------------------------------------------------------------
 // AvgPool2d(2,2): H, W of the INPUT (floor semantics for odd sizes)
+// `scale` = 0.25 for the average pool and its adjoint; with scale = 1 the two branches are the adjoint pair of
+// nn.Upsample(scale_factor=2, mode='nearest'): BWD = replicate 2x2 (upsample forward), !BWD = sum 2x2 (its gradient)
 template <bool BF16, bool BWD>
 __global__ void avgpool2_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H, int W,
-                                int cchunks) {
+                                int cchunks, float scale) {
   constexpr int V = Elem<BF16>::V;
   const int Ho = H / 2, Wo = W / 2;
   if constexpr (!BWD) {
@@ -170,7 +172,7 @@ __global__ void avgpool2_kernel(const u32x4* __restrict__ src, u32x4* __restrict
           for (int e = 0; e < V; e++) a[e] += f[e];
         }
 #pragma unroll
-      for (int e = 0; e < V; e++) a[e] *= 0.25f;
+      for (int e = 0; e < V; e++) a[e] *= scale;
       dst[i] = Elem<BF16>::pack(a);
     }
   } else {
@@ -188,7 +190,7 @@ __global__ void avgpool2_kernel(const u32x4* __restrict__ src, u32x4* __restrict
       if (h / 2 < Ho && w / 2 < Wo) {
         Elem<BF16>::unpack(src[(((long)n * Ho + h / 2) * Wo + w / 2) * cchunks + cq], a);
 #pragma unroll
-        for (int e = 0; e < V; e++) a[e] *= 0.25f;
+        for (int e = 0; e < V; e++) a[e] *= scale;
       }
       dst[i] = Elem<BF16>::pack(a);
     }
@@ -268,11 +270,32 @@ __global__ void avgpool3s2_kernel(const u32x4* __restrict__ src, u32x4* __restri
     return 0;                                                                                              \
   } while (0)
 
+#define POOL2_LAUNCH(BWD, total, scale)                                                                    \
+  do {                                                                                                     \
+    const int V = dtype == MT_BF16 ? 8 : 4;                                                                \
+    const int cchunks = Cp / V;                                                                            \
+    if ((total) == 0) return 0;                                                                            \
+    if (dtype == MT_BF16)                                                                                  \
+      hipLaunchKernelGGL((avgpool2_kernel<true, BWD>), dim3(EW_GRID((long)(total) * cchunks)), dim3(256), 0, (hipStream_t)s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, scale); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((avgpool2_kernel<false, BWD>), dim3(EW_GRID((long)(total) * cchunks)), dim3(256), 0, (hipStream_t)s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, scale); \
+    MT_LAUNCH_CHECK();                                                                                     \
+    return 0;                                                                                              \
+  } while (0)
 extern "C" int mt_avgpool2_fwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s) {
-  POOL_LAUNCH(avgpool2_kernel, false, (long)N * (H / 2) * (W / 2));
+  POOL2_LAUNCH(false, (long)N * (H / 2) * (W / 2), 0.25f);
 }
 extern "C" int mt_avgpool2_bwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s) {
-  POOL_LAUNCH(avgpool2_kernel, true, (long)N * H * W);
+  POOL2_LAUNCH(true, (long)N * H * W, 0.25f);
+}
+// nn.Upsample(scale_factor=2, mode='nearest') (blocks.py:75): H, W are the sizes of the UPSAMPLED tensor (even)
+extern "C" int mt_upsample2_fwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s) {
+  MT_CHECK(H % 2 == 0 && W % 2 == 0, "upsample2: output size %dx%d must be even", H, W);
+  POOL2_LAUNCH(true, (long)N * H * W, 1.0f);
+}
+extern "C" int mt_upsample2_bwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s) {
+  MT_CHECK(H % 2 == 0 && W % 2 == 0, "upsample2: output size %dx%d must be even", H, W);
+  POOL2_LAUNCH(false, (long)N * (H / 2) * (W / 2), 1.0f);
 }
 extern "C" int mt_avgpool3s2_fwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s) {
   POOL_LAUNCH(avgpool3s2_kernel, false, (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1));

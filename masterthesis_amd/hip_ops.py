@@ -696,6 +696,32 @@ class _Pool(torch.autograd.Function):
         return dx, None
 
 
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = canon(x)
+        N, Cc, H, W = x.shape
+        y = new_act(N, Cc, 2 * H, 2 * W, x.dtype, x.device)
+        L.check(L.load().mt_upsample2_fwd(_mt(x.dtype), _ptr(x), _ptr(y), N, 2 * H, 2 * W, padc(Cc), _stream()),
+                "mt_upsample2_fwd")
+        ctx.shape = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W = ctx.shape
+        dy = canon(dy)
+        dx = new_act(N, Cc, H, W, dy.dtype, dy.device)
+        L.check(L.load().mt_upsample2_bwd(_mt(dy.dtype), _ptr(dy), _ptr(dx), N, 2 * H, 2 * W, padc(Cc), _stream()),
+                "mt_upsample2_bwd")
+        return dx
+
+
+def upsample2_nearest(x):
+    """nn.Upsample(scale_factor=2, mode='nearest')"""
+    return _Upsample2.apply(x)
+
+
 def avg_pool2(x):
     """nn.AvgPool2d(kernel_size=2, stride=2)"""
     return _Pool.apply(x, 2)

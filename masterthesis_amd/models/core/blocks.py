@@ -83,34 +83,50 @@ class ConvBlock(nn.Module):
 
 
 class UpsampleBlock(nn.Module):
-    """ConvTranspose2d -> norm -> activation (reference blocks.py:48-91; only up_type 'transpose')."""
+    """up_type 'transpose': ConvTranspose2d -> norm -> activation; 'nearest': nn.Upsample(x2) -> ConvBlock (stride 1,
+    zero padding -- the padding factory receives the already-resolved ``None``) -> norm -> activation
+    (reference blocks.py:48-91; 'pixelshuffle' is not implemented)."""
 
     def __init__(self, input_dim, output_dim, kernel_size, stride=1, padding=0, output_padding=0, bias=False,
                  norm_layer=None, activation=None, padding_type=None, sn=False, up_type="transpose"):
         super().__init__()
-        if "transpose" not in up_type:
-            raise NotImplementedError(f"Mode {up_type} is not supported at the moment")
         if sn:
             spectral_norm(None)
         self.act = get_activation_layer(activation)
         self.norm = get_norm_layer(norm_layer)
         self.stride, self.padding, self.output_padding = stride, padding, output_padding
-        mods = [nn.ConvTranspose2d(input_dim, output_dim, kernel_size, stride, padding, output_padding, bias=bias)]
+        self.nearest = "transpose" not in up_type
+        if "transpose" in up_type:
+            mods = [nn.ConvTranspose2d(input_dim, output_dim, kernel_size, stride, padding, output_padding, bias=bias)]
+        elif "nearest" in up_type:
+            get_padding_layer(padding_type)       # (raises for unsupported types like the reference)
+            mods = [_Marker("upsample_nearest", 2),
+                    ConvBlock(input_dim, output_dim, kernel_size, 1, padding, padding_type=None, bias=bias, sn=sn)]
+        else:
+            raise NotImplementedError(f"Mode {up_type} is not supported at the moment")
+        self._ni = None
         if self.norm is not None:
+            self._ni = len(mods)
             mods.append(_make_norm(self.norm, output_dim))
         if self.act is not None:
             mods.append(_Marker(self.act))
         self.block = nn.Sequential(*mods)
 
     def forward(self, x):
-        conv = self.block[0]
         fused_act = self.act if self.norm is None else None
-        y = ops.conv_transpose2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
-                                 out_pad=self.output_padding, act=fused_act)
+        if self.nearest:
+            inner = self.block[1]
+            conv = inner.block[inner._ci]
+            y = ops.conv2d(ops.upsample2_nearest(x), conv.weight, conv.bias, stride=1, pad=inner.padding,
+                           pad_mode="zero", act=fused_act)
+        else:
+            conv = self.block[0]
+            y = ops.conv_transpose2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+                                     out_pad=self.output_padding, act=fused_act)
         if self.norm == "instance":
             return ops.instance_norm_act(y, act=self.act)
         if self.norm == "layer":
-            return self.block[1](y, act=self.act)
+            return self.block[self._ni](y, act=self.act)
         return y
 
 

@@ -116,8 +116,16 @@ def _upsampling(dim, output_dim, num_ups, up_type, norm_layer, activation, bias)
         ups.append(UpsampleBlock(dim, dim // 2, 3, 2, 1, 1, norm_layer=norm_layer, activation=activation,
                                  up_type=up_type, bias=bias))
         dim = dim // 2
-    ups.append(UpsampleBlock(dim, output_dim, 1, 1, 0, activation="tanh", up_type="transpose"))
+    ups.append(_to_rgb(dim, output_dim, up_type))
     return nn.Sequential(*ups)
+
+
+def _to_rgb(dim, output_dim, up_type):
+    """last decoder layer (networks.py:185-188): 1x1 ConvTranspose + tanh, or 7x7 zero-padded conv + tanh for the
+    non-transpose up-sampling types"""
+    if "transpose" in up_type:
+        return UpsampleBlock(dim, output_dim, 1, 1, 0, activation="tanh", up_type="transpose")
+    return ConvBlock(dim, output_dim, 7, 1, 3, activation="tanh")
 
 
 class Decoder(nn.Module):
@@ -179,7 +187,7 @@ class DecoderConcat(nn.Module):
         self.dec3 = UpsampleBlock(nch, nch // 2, 3, 2, 1, 1, norm_layer=norm_layer, activation=activation,
                                   up_type=up_type, bias=bias)
         nch = nch // 2 + latent_dim
-        self.dec4 = UpsampleBlock(nch, output_dim, 1, 1, 0, activation="tanh", up_type="transpose")
+        self.dec4 = _to_rgb(nch, output_dim, up_type)
 
     def forward(self, x, z, c):
         dt = ops.compute_dtype()

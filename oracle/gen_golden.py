@@ -254,6 +254,9 @@ def main():
     if want("adain_step_hinge"):
         step_case("adain_step_hinge", "AdaINModel", steps=1, seed=5, num_domains=2, batch_size=1, dim=4,
                   gan_mode="hinge")
+    if want("adain_step_nearest"):
+        step_case("adain_step_nearest", "AdaINModel", steps=1, seed=7, num_domains=2, batch_size=1, dim=4,
+                  up_type="nearest")
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)

@@ -276,6 +276,22 @@ def test_elementwise_and_pools(dtype, hip_device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample2_nearest(dtype, hip_device):
+    """nn.Upsample(scale_factor=2, mode='nearest') (--up_type nearest), forward and gradient"""
+    ops = _ops(dtype)
+    for shape in ((2, 16, 6, 5), (1, 5, 3, 7)):
+        x = _rnd(*shape, seed=21)
+        xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+        yr = F.interpolate(xr, scale_factor=2, mode="nearest")
+        y = ops.upsample2_nearest(xd)
+        g = _rnd(*yr.shape, seed=22)
+        yr.backward(g)
+        y.backward(g.to(hip_device))
+        _close(y, yr, dtype, what="upsample2")
+        _close(xd.grad, xr.grad, dtype, what="upsample2 dx", scale=4.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layout_cat_noise(dtype, hip_device):
     ops = _ops(dtype)
     x = _rnd(3, 3, 8, 6, seed=1)
