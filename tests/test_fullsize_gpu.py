@@ -133,3 +133,42 @@ def test_full_size_step_runs_and_is_finite(ms_dis, tmp_path, hip_device):
         after = torch.cat([p.detach().flatten()[:1000].float() for p in M.model[n].parameters()])
         assert torch.isfinite(after).all(), f"{n} has non-finite parameters"
         assert (after - before[n]).abs().max().item() > 0, f"{n} did not move"
+
+
+def test_short_training_run_bf16_tracks_fp32(tmp_path, hip_device):
+    """80 optimisation steps (128x128, 4 pairs, dim 64) in bf16 and in fp32 from the same seed: the reconstruction
+    losses must go down and the bf16 trajectory must stay within a few percent of the fp32 one."""
+    import argparse
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from masterthesis_amd import models
+    from masterthesis_amd.dataset import SyntheticDataset
+    out = {}
+    for prec in ("bf16", "fp32"):
+        o = argparse.Namespace(precision=prec, num_domains=2, batch_size=4, crop_size=128, ms_dis=False)
+        args = bench.model_args(o, str(tmp_path / prec))
+        torch.manual_seed(0)
+        M = models.AdaINModel(args)
+        M.initialize()
+        ds = SyntheticDataset(args, length=16, seed=5)
+        batches = []
+        for b in range(4):
+            items = [ds[b * 4 + i] for i in range(4)]
+            batches.append({k: torch.stack([it[k] for it in items]).to(hip_device) for k in items[0]})
+        first = None
+        for it in range(80):
+            M.update_lr()
+            M.set_inputs(batches[it % 4])
+            M.optimize_parameters(it)
+            if it == 3:
+                first = dict(M.sync_losses())
+        out[prec] = (first, dict(M.sync_losses()))
+        for n in M.model:
+            assert all(torch.isfinite(p).all() for p in M.model[n].parameters()), f"{prec}: {n} has non-finite weights"
+    for prec, (first, last) in out.items():
+        assert last["l1_self_rec"] < first["l1_self_rec"] and last["total_g"] < first["total_g"], (prec, first, last)
+    for k in ("total_g", "l1_self_rec", "l1_cc_rec", "d_total"):
+        a, b = out["bf16"][1][k], out["fp32"][1][k]
+        assert abs(a - b) <= 0.10 * abs(b) + 0.05, f"{k}: bf16 {a} vs fp32 {b} after 80 steps"
