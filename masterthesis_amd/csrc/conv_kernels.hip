@@ -770,386 +770,3 @@ int mt_launch_wgrad(int dtype, const WgradParams& pin, int nsplit, hipStream_t s
   MT_LAUNCH_CHECK();
   return 0;
 }
-
-// ------------------------------------------------------------------------------------------
-// weight (un)packing between the reference layouts and [row][tap][col] tiles
-// ------------------------------------------------------------------------------------------
-// pack[r][t][c] = (r<R && c<C) ? w[r*sr + c*sc + kh[t]*kW + kw[t]] : 0, r<Rp, c<Cp
-template <bool BF16>
-__global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out, PackParams p) {
-  const long total = (long)p.Rp * p.ntaps * p.Cp;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % p.Cp);
-    const long rt = i / p.Cp;
-    const int t = (int)(rt % p.ntaps);
-    const int r = (int)(rt / p.ntaps);
-    float v = 0.f;
-    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
-    if constexpr (BF16) reinterpret_cast<unsigned short*>(out)[i] = f32_to_bf16_bits(v);
-    else reinterpret_cast<float*>(out)[i] = v;
-  }
-}
-// batched variant: the table lives in device memory (built once per network, addresses are stable)
-__global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
-  int lo = 0, hi = n - 1;                       // entry whose block range holds blockIdx.x
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int)blockIdx.x >= tab[mid].blk0) lo = mid; else hi = mid - 1;
-  }
-  const PackEntry& e = tab[lo];
-  const PackParams& p = e.p;
-  const long total = (long)p.Rp * p.ntaps * p.Cp;
-  const float* __restrict__ w = e.w;
-  for (long i = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; i < total; i += (long)e.nblk * blockDim.x) {
-    const int c = (int)(i % p.Cp);
-    const long rt = i / p.Cp;
-    const int t = (int)(rt % p.ntaps);
-    const int r = (int)(rt / p.ntaps);
-    float v = 0.f;
-    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
-    if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[i] = f32_to_bf16_bits(v);
-    else reinterpret_cast<float*>(e.out)[i] = v;
-  }
-}
-int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s) {
-  if (n <= 0 || total_blocks <= 0) return 0;
-  hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, s, dev_table, n);
-  MT_LAUNCH_CHECK();
-  return 0;
-}
-int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s) {
-  const long total = (long)p.Rp * p.ntaps * p.Cp;
-  if (total == 0) return 0;
-  const int blocks = (int)min((long)4096, (total + 255) / 256);
-  if (dtype == MT_BF16) hipLaunchKernelGGL((pack_kernel<true>), dim3(blocks), dim3(256), 0, s, w, out, p);
-  else hipLaunchKernelGGL((pack_kernel<false>), dim3(blocks), dim3(256), 0, s, w, out, p);
-  MT_LAUNCH_CHECK();
-  return 0;
-}
-// dw[r*sr + c*sc + kh[t]*kW + kw[t]] = sum_split src[split][r][t][c]   (r<R, c<C; src rows have Cp columns)
-__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p, int nsplit,
-                              long slab, int accumulate) {
-  // one thread = 4 consecutive packed columns (16-byte reads from every split slab)
-  const int c4n = p.Cp >> 2;
-  const long total = (long)p.R * p.ntaps * c4n;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const long rt = i / c4n;
-    const int t = (int)(rt % p.ntaps);
-    const int r = (int)(rt / p.ntaps);
-    const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
-    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int c = c4 * 4 + e;
-      if (c < p.C) {
-        float* o = d + (long)c * p.sc;
-        *o = accumulate ? *o + a[e] : a[e];
-      }
-    }
-  }
-}
-// Many splits of a small weight tensor (stem / to-RGB layers: up to 512 slabs of ~100 KB): one WAVE per 4
-// packed columns, lanes stride over the split slabs (64 loads in flight instead of a serial chain), wave sum.
-__global__ __launch_bounds__(256) void unpack_wave_kernel(const float* __restrict__ src, float* __restrict__ dw,
-                                                          PackParams p, int nsplit, long slab, int accumulate) {
-  const int c4n = p.Cp >> 2;
-  const long total = (long)p.R * p.ntaps * c4n;
-  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= total) return;
-  const int c4 = (int)(i % c4n);
-  const long rt = i / c4n;
-  const int t = (int)(rt % p.ntaps);
-  const int r = (int)(rt / p.ntaps);
-  const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int k = lane; k < nsplit; k += 64) a += q[(long)k * (slab >> 2)];
-#pragma unroll
-  for (int e = 0; e < 4; e++) a[e] = wave_sum(a[e]);
-  if (lane == 0) {
-    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int c = c4 * 4 + e;
-      if (c < p.C) {
-        float* o = d + (long)c * p.sc;
-        *o = accumulate ? *o + a[e] : a[e];
-      }
-    }
-  }
-}
-// Fast path (sc == ntaps, natural tap order -- every weight-gradient unpack): for a fixed row r the output
-// [c][kh][kw] is one contiguous run, so a block sums the split slabs for 64 columns with coalesced reads,
-// transposes [t][c] -> [c][t] through LDS and writes a contiguous run.
-__global__ __launch_bounds__(256) void unpack_t_kernel(const float* __restrict__ src, float* __restrict__ dw,
-                                                       PackParams p, int nsplit, long slab, int accumulate) {
-  __shared__ float tile[64 * MT_MAX_TAPS + 64];
-  const int r = blockIdx.x, c0 = blockIdx.y * 64, nt = p.ntaps;
-  const int ncl = min(64, p.Cp - c0);
-  const float* base = src + ((long)r * nt) * p.Cp + c0;
-  for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
-    const int t = idx >> 6, cl = idx & 63;
-    float a = 0.f;
-    if (cl < ncl) {
-      const float* q = base + (long)t * p.Cp + cl;
-      for (int k = 0; k < nsplit; k++) a += q[(long)k * slab];
-    }
-    tile[cl * nt + t + (cl >> 5)] = a;      // +1 float of padding per 32 columns against bank conflicts
-  }
-  __syncthreads();
-  const int nvalid = min(64, p.C - c0);
-  float* out = dw + (long)r * p.sr + (long)c0 * nt;
-  for (int idx = threadIdx.x; idx < nvalid * nt; idx += 256) {
-    const int cl = idx / nt;
-    const float v = tile[idx + (cl >> 5)];
-    out[idx] = accumulate ? out[idx] + v : v;
-  }
-}
-int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
-                     hipStream_t s) {
-  const long total = (long)p.R * p.ntaps * (p.Cp >> 2);
-  if (total == 0) return 0;
-  bool natural = (p.sc == p.ntaps);
-  for (int t = 0; t < p.ntaps && natural; t++) natural = (p.kh[t] * p.kW + p.kw[t] == t);
-  // the transposing kernel needs enough (row, 64-column) blocks to fill the chip; tiny weight tensors with
-  // many splits keep the element-parallel kernel
-  if (natural && nsplit <= 4 && (long)p.R * cdiv(p.Cp, 64) >= 512) {
-    hipLaunchKernelGGL(unpack_t_kernel, dim3(p.R, cdiv(p.Cp, 64)), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
-  } else if (nsplit >= 32 && total <= 65536) {
-    hipLaunchKernelGGL(unpack_wave_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, src, dw, p, nsplit, slab,
-                       accumulate);
-  } else {
-    const int blocks = (int)min((long)4096, (total + 255) / 256);
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
-  }
-  MT_LAUNCH_CHECK();
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// adjoint of ReflectionPad2d: fold the gradient of the padded map back onto the interior.
-// src: [N][H+2P][W+2P][Cp], dst: [N][H][W][Cp]
-// ------------------------------------------------------------------------------------------
-template <bool BF16>
-__global__ void reflect_fold_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H,
-                                    int W, int cchunks, int P) {
-  const long total = (long)N * H * W * cchunks;
-  const int Hp = H + 2 * P, Wp = W + 2 * P;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % cchunks);
-    long t = i / cchunks;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
-    // pre-images of h in padded coordinates
-    int hs[3], ws[3], nh = 0, nw = 0;
-    hs[nh++] = h + P;
-    if (h >= 1 && h <= P) hs[nh++] = P - h;
-    if (h <= H - 2 && h >= H - 1 - P) hs[nh++] = P + 2 * (H - 1) - h;
-    ws[nw++] = w + P;
-    if (w >= 1 && w <= P) ws[nw++] = P - w;
-    if (w <= W - 2 && w >= W - 1 - P) ws[nw++] = P + 2 * (W - 1) - w;
-    float accv[Elem<BF16>::V];
-#pragma unroll
-    for (int e = 0; e < Elem<BF16>::V; e++) accv[e] = 0.f;
-    for (int a = 0; a < nh; a++)
-      for (int b = 0; b < nw; b++) {
-        const u32x4 v = src[(((long)n * Hp + hs[a]) * Wp + ws[b]) * cchunks + cq];
-        float f[Elem<BF16>::V];
-        Elem<BF16>::unpack(v, f);
-#pragma unroll
-        for (int e = 0; e < Elem<BF16>::V; e++) accv[e] += f[e];
-      }
-    dst[i] = Elem<BF16>::pack(accv);
-  }
-}
-int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
-                           hipStream_t s) {
-  const int V = dtype == MT_BF16 ? 8 : 4;
-  const int cchunks = Cp / V;
-  const long total = (long)N * H * W * cchunks;
-  if (total == 0) return 0;
-  const int blocks = (int)min((long)65535, (total + 255) / 256);
-  if (dtype == MT_BF16)
-    hipLaunchKernelGGL((reflect_fold_kernel<true>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
-  else
-    hipLaunchKernelGGL((reflect_fold_kernel<false>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P);
-  MT_LAUNCH_CHECK();
-  return 0;
-}
-
-// Border-only variant for the stride-1 path: dst already holds the interior part (pre-image (h+P, w+P)); add
-// the other pre-images, which all lie in the P-wide ring of the padded map.  Only pixels within P of a border
-// (excluding the outermost row / column, which reflection never hits) have any.
-template <bool BF16>
-__global__ void ring_fold_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H, int W,
-                                 int cchunks, int P, int band) {
-  const int Hp = H + 2 * P, Wp = W + 2 * P;
-  // band != 0 (H, W >= 2P+2): enumerate only the pixels that have a ring pre-image -- 2P full rows, then 2P
-  // columns of the remaining H-2P rows; otherwise scan every pixel
-  const int nrowpix = 2 * P * W;
-  const int per_img = band ? nrowpix + (H - 2 * P) * 2 * P : H * W;
-  const long total = (long)N * per_img * cchunks;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % cchunks);
-    long t = i / cchunks;
-    const int j = (int)(t % per_img);
-    const int n = (int)(t / per_img);
-    int h, w;
-    if (!band) {
-      h = j / W; w = j - h * W;
-    } else if (j < nrowpix) {
-      const int r = j / W;
-      w = j - r * W;
-      h = r < P ? 1 + r : H - 1 - P + (r - P);
-    } else {
-      const int jj = j - nrowpix;
-      const int rr = jj / (2 * P), wc = jj - rr * (2 * P);
-      h = rr == 0 ? 0 : (rr == H - 2 * P - 1 ? H - 1 : P + rr);
-      w = wc < P ? 1 + wc : W - 1 - P + (wc - P);
-    }
-    int hs[3], ws[3], nh = 0, nw = 0;
-    hs[nh++] = h + P;
-    if (h >= 1 && h <= P) hs[nh++] = P - h;
-    if (h <= H - 2 && h >= H - 1 - P) hs[nh++] = P + 2 * (H - 1) - h;
-    ws[nw++] = w + P;
-    if (w >= 1 && w <= P) ws[nw++] = P - w;
-    if (w <= W - 2 && w >= W - 1 - P) ws[nw++] = P + 2 * (W - 1) - w;
-    if (nh * nw == 1) continue;
-    const long di = (((long)n * H + h) * W + w) * cchunks + cq;
-    float accv[Elem<BF16>::V];
-    Elem<BF16>::unpack(dst[di], accv);
-    for (int a = 0; a < nh; a++)
-      for (int b = 0; b < nw; b++) {
-        if (a == 0 && b == 0) continue;
-        const u32x4 v = src[(((long)n * Hp + hs[a]) * Wp + ws[b]) * cchunks + cq];
-        float f[Elem<BF16>::V];
-        Elem<BF16>::unpack(v, f);
-#pragma unroll
-        for (int e = 0; e < Elem<BF16>::V; e++) accv[e] += f[e];
-      }
-    dst[di] = Elem<BF16>::pack(accv);
-  }
-}
-int mt_launch_ring_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P, hipStream_t s) {
-  const int V = dtype == MT_BF16 ? 8 : 4;
-  const int cchunks = Cp / V;
-  const int band = (H >= 2 * P + 2 && W >= 2 * P + 2) ? 1 : 0;
-  const long per_img = band ? (long)2 * P * W + (long)(H - 2 * P) * 2 * P : (long)H * W;
-  const long total = (long)N * per_img * cchunks;
-  if (total == 0) return 0;
-  const int blocks = (int)min((long)65535, (total + 255) / 256);
-  if (dtype == MT_BF16)
-    hipLaunchKernelGGL((ring_fold_kernel<true>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P, band);
-  else
-    hipLaunchKernelGGL((ring_fold_kernel<false>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, cchunks, P, band);
-  MT_LAUNCH_CHECK();
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// bias gradient: db[c] = sum over pixels of dy[pixel][c].  Two launches, no atomics (512 blocks adding into
-// the same C addresses serialise: ~100 us): blocks write fp32 partial rows, a small kernel adds them up.
-// ------------------------------------------------------------------------------------------
-template <bool BF16>
-__global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ part, long npix,
-                                                     long cchunks_, long pix_per_block) {
-  constexpr int V = Elem<BF16>::V;
-  __shared__ float red[256];
-  const int cchunks = (int)cchunks_;
-  const int cq = threadIdx.x % cchunks;
-  const int pl = threadIdx.x / cchunks;
-  const int npl = blockDim.x / cchunks;
-  const long p0 = (long)blockIdx.x * pix_per_block;
-  const long p1 = min(npix, p0 + pix_per_block);
-  float accv[V];
-#pragma unroll
-  for (int e = 0; e < V; e++) accv[e] = 0.f;
-  if (pl < npl) {
-    // 4 independent 16-byte loads in flight per thread (a dependent one-at-a-time loop is latency bound)
-    long px = p0 + pl;
-    for (; px + 3 * (long)npl < p1; px += 4 * (long)npl) {
-      const u32x4 v0 = dy[px * cchunks + cq];
-      const u32x4 v1 = dy[(px + npl) * cchunks + cq];
-      const u32x4 v2 = dy[(px + 2 * (long)npl) * cchunks + cq];
-      const u32x4 v3 = dy[(px + 3 * (long)npl) * cchunks + cq];
-      float f0[V], f1[V], f2[V], f3[V];
-      Elem<BF16>::unpack(v0, f0);
-      Elem<BF16>::unpack(v1, f1);
-      Elem<BF16>::unpack(v2, f2);
-      Elem<BF16>::unpack(v3, f3);
-#pragma unroll
-      for (int e = 0; e < V; e++) accv[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
-    }
-    for (; px < p1; px += npl) {
-      float f[V];
-      Elem<BF16>::unpack(dy[px * cchunks + cq], f);
-#pragma unroll
-      for (int e = 0; e < V; e++) accv[e] += f[e];
-    }
-  } else {
-    // threads beyond the last whole pixel lane contribute zeros (their tid % cchunks still names a chunk)
-  }
-#pragma unroll
-  for (int e = 0; e < V; e++) {
-    const float a = block_sum_by_chunk(accv[e], cchunks, red);
-    if (threadIdx.x < cchunks) part[(long)blockIdx.x * cchunks * V + threadIdx.x * V + e] = a;
-  }
-}
-// 64 channels x 16 row groups per block: the partial rows are summed 16-way in parallel (one thread walking
-// 512 rows is a 90 us dependent-load chain)
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db,
-                                                            int nblk, int Cp, int C, int accumulate) {
-  __shared__ float red[1024];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float a0 = 0.f, a1 = 0.f;
-  if (c < C) {
-    int b = g;
-#pragma unroll 4
-    for (; b + 16 < nblk; b += 32) {
-      a0 += part[(long)b * Cp + c];
-      a1 += part[(long)(b + 16) * Cp + c];
-    }
-    if (b < nblk) a0 += part[(long)b * Cp + c];
-  }
-  red[threadIdx.x] = a0 + a1;
-  __syncthreads();
-  if (g == 0 && c < C) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) a += red[k * 64 + cl];
-    db[c] = accumulate ? db[c] + a : a;
-  }
-}
-size_t mt_colsum_ws_bytes(int Cp) { return (size_t)512 * Cp * sizeof(float); }
-int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
-                     size_t ws_bytes, hipStream_t s) {
-  const int V = dtype == MT_BF16 ? 8 : 4;
-  const int cchunks = Cp / V;
-  MT_CHECK(cchunks <= 256, "colsum: too many channels %d", Cp);
-  MT_CHECK(ws != nullptr && ws_bytes >= mt_colsum_ws_bytes(Cp), "colsum: workspace too small");
-  const int threads = 256;
-  const int npl = threads / cchunks;
-  // at most 512 blocks (one row of partials each), at least 16 pixels per thread
-  long ppb = (npix + 511) / 512;
-  if (ppb < (long)npl * 16) ppb = (long)npl * 16;
-  ppb = (ppb + npl - 1) / npl * npl;
-  const int blocks = (int)((npix + ppb - 1) / ppb);
-  if (blocks > 0) {
-    if (dtype == MT_BF16)
-      hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
-                         (long)cchunks, ppb);
-    else
-      hipLaunchKernelGGL((colsum_kernel<false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
-                         (long)cchunks, ppb);
-    MT_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const float*)ws, db, blocks, Cp, C,
-                     accumulate);
-  MT_LAUNCH_CHECK();
-  return 0;
-}

@@ -1,0 +1,163 @@
+// Weight layout kernels: reference OIHW / IOHW fp32 weights <-> the packed [row][tap][channel] GEMM images
+// (pack, batched pack of a whole network), and the weight-gradient slabs back to the reference layout
+// (unpack: sums the pixel-split slabs, optionally accumulating into param.grad).
+#include "mt_common.h"
+#include "conv_params.h"
+
+// ------------------------------------------------------------------------------------------
+// weight (un)packing between the reference layouts and [row][tap][col] tiles
+// ------------------------------------------------------------------------------------------
+// pack[r][t][c] = (r<R && c<C) ? w[r*sr + c*sc + kh[t]*kW + kw[t]] : 0, r<Rp, c<Cp
+template <bool BF16>
+__global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out, PackParams p) {
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if constexpr (BF16) reinterpret_cast<unsigned short*>(out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(out)[i] = v;
+  }
+}
+// batched variant: the table lives in device memory (built once per network, addresses are stable)
+__global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;                       // entry whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= tab[mid].blk0) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry& e = tab[lo];
+  const PackParams& p = e.p;
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  const float* __restrict__ w = e.w;
+  for (long i = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; i < total; i += (long)e.nblk * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(e.out)[i] = v;
+  }
+}
+int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s) {
+  if (n <= 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, s, dev_table, n);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s) {
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long)4096, (total + 255) / 256);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((pack_kernel<true>), dim3(blocks), dim3(256), 0, s, w, out, p);
+  else hipLaunchKernelGGL((pack_kernel<false>), dim3(blocks), dim3(256), 0, s, w, out, p);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+// dw[r*sr + c*sc + kh[t]*kW + kw[t]] = sum_split src[split][r][t][c]   (r<R, c<C; src rows have Cp columns)
+__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dw, PackParams p, int nsplit,
+                              long slab, int accumulate) {
+  // one thread = 4 consecutive packed columns (16-byte reads from every split slab)
+  const int c4n = p.Cp >> 2;
+  const long total = (long)p.R * p.ntaps * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long rt = i / c4n;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
+    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c4 * 4 + e;
+      if (c < p.C) {
+        float* o = d + (long)c * p.sc;
+        *o = accumulate ? *o + a[e] : a[e];
+      }
+    }
+  }
+}
+// Many splits of a small weight tensor (stem / to-RGB layers: up to 512 slabs of ~100 KB): one WAVE per 4
+// packed columns, lanes stride over the split slabs (64 loads in flight instead of a serial chain), wave sum.
+__global__ __launch_bounds__(256) void unpack_wave_kernel(const float* __restrict__ src, float* __restrict__ dw,
+                                                          PackParams p, int nsplit, long slab, int accumulate) {
+  const int c4n = p.Cp >> 2;
+  const long total = (long)p.R * p.ntaps * c4n;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  const long rt = i / c4n;
+  const int t = (int)(rt % p.ntaps);
+  const int r = (int)(rt / p.ntaps);
+  const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < nsplit; k += 64) a += q[(long)k * (slab >> 2)];
+#pragma unroll
+  for (int e = 0; e < 4; e++) a[e] = wave_sum(a[e]);
+  if (lane == 0) {
+    float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = c4 * 4 + e;
+      if (c < p.C) {
+        float* o = d + (long)c * p.sc;
+        *o = accumulate ? *o + a[e] : a[e];
+      }
+    }
+  }
+}
+// Fast path (sc == ntaps, natural tap order -- every weight-gradient unpack): for a fixed row r the output
+// [c][kh][kw] is one contiguous run, so a block sums the split slabs for 64 columns with coalesced reads,
+// transposes [t][c] -> [c][t] through LDS and writes a contiguous run.
+__global__ __launch_bounds__(256) void unpack_t_kernel(const float* __restrict__ src, float* __restrict__ dw,
+                                                       PackParams p, int nsplit, long slab, int accumulate) {
+  __shared__ float tile[64 * MT_MAX_TAPS + 64];
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, nt = p.ntaps;
+  const int ncl = min(64, p.Cp - c0);
+  const float* base = src + ((long)r * nt) * p.Cp + c0;
+  for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
+    const int t = idx >> 6, cl = idx & 63;
+    float a = 0.f;
+    if (cl < ncl) {
+      const float* q = base + (long)t * p.Cp + cl;
+      for (int k = 0; k < nsplit; k++) a += q[(long)k * slab];
+    }
+    tile[cl * nt + t + (cl >> 5)] = a;      // +1 float of padding per 32 columns against bank conflicts
+  }
+  __syncthreads();
+  const int nvalid = min(64, p.C - c0);
+  float* out = dw + (long)r * p.sr + (long)c0 * nt;
+  for (int idx = threadIdx.x; idx < nvalid * nt; idx += 256) {
+    const int cl = idx / nt;
+    const float v = tile[idx + (cl >> 5)];
+    out[idx] = accumulate ? out[idx] + v : v;
+  }
+}
+int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
+                     hipStream_t s) {
+  const long total = (long)p.R * p.ntaps * (p.Cp >> 2);
+  if (total == 0) return 0;
+  bool natural = (p.sc == p.ntaps);
+  for (int t = 0; t < p.ntaps && natural; t++) natural = (p.kh[t] * p.kW + p.kw[t] == t);
+  // the transposing kernel needs enough (row, 64-column) blocks to fill the chip; tiny weight tensors with
+  // many splits keep the element-parallel kernel
+  if (natural && nsplit <= 4 && (long)p.R * cdiv(p.Cp, 64) >= 512) {
+    hipLaunchKernelGGL(unpack_t_kernel, dim3(p.R, cdiv(p.Cp, 64)), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  } else if (nsplit >= 32 && total <= 65536) {
+    hipLaunchKernelGGL(unpack_wave_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, src, dw, p, nsplit, slab,
+                       accumulate);
+  } else {
+    const int blocks = (int)min((long)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, s, src, dw, p, nsplit, slab, accumulate);
+  }
+  MT_LAUNCH_CHECK();
+  return 0;
+}
