@@ -151,6 +151,18 @@ int mt_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, in
  * fwd: src [N][H/2][W/2][Cp] -> dst [N][H][W][Cp]; bwd: src = d(upsampled) [N][H][W][Cp] -> dst [N][H/2][W/2][Cp]. */
 int mt_upsample2_fwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_upsample2_bwd(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, mt_stream_t s);
+/* Spectral normalisation of a conv weight (--dis_sn; functions.py:113-121 -> torch.nn.utils.spectral_norm with
+ * n_power_iterations=1, eps=1e-12, dim=0; blocks.py:33-34).  W: fp32 [rows = Cout][cols = Cin*kh*kw].
+ * power_iter: n_iter times { v <- normalize(W^T u); u <- normalize(W v) } in place, then sigma[0] = u . (W v);
+ *             n_iter = 0 (eval mode) only evaluates sigma with the stored u, v.
+ * scale_fwd : Weff = W / sigma.     scale_bwd: dW = (G - <G, Weff> u v^T) / sigma   (u, v constants).
+ * ws: mt_sn_ws_bytes(rows, cols) bytes. */
+size_t mt_sn_ws_bytes(int rows, int cols);
+int mt_sn_power_iter(const float* W, float* u, float* v, float* sigma, int rows, int cols, int n_iter, float eps,
+                     void* ws, size_t ws_bytes, mt_stream_t s);
+int mt_sn_scale_fwd(const float* W, const float* sigma, float* Weff, long n, mt_stream_t s);
+int mt_sn_scale_bwd(const float* G, const float* Weff, const float* u, const float* v, const float* sigma, float* dW,
+                    int rows, int cols, void* ws, size_t ws_bytes, mt_stream_t s);
 /* AvgPool2d(3, stride 2, pad 1, count_include_pad=False) (networks.py:447) */
 int mt_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);

@@ -68,6 +68,10 @@ SIGNATURES = {
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_sn_ws_bytes": (_z, [_i, _i]),
+    "mt_sn_power_iter": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _z, _p]),
+    "mt_sn_scale_fwd": (_i, [_p, _p, _p, C.c_long, _p]),
+    "mt_sn_scale_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _z, _p]),
     "mt_avgpool3s2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool3s2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_gap_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),

@@ -283,7 +283,7 @@ def set_fused_grad_accumulation(on):
 
 def _fused_grad_target(p):
     """param.grad if gradients may be accumulated into it in place by the backward kernel, else None"""
-    g = None if p is None else p.grad
+    g = None if (p is None or not p.is_leaf) else p.grad
     ok = (_FUSE_WGRAD_ACC[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous()
           and g.shape == p.shape and g.is_cuda)
     return g if ok else None
@@ -455,6 +455,53 @@ def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None,
     """nn.ConvTranspose2d (+ activation); weight layout [Cin, Cout, kh, kw]."""
     return _Conv.apply(x, weight, bias, (stride, pad, L.PAD_ZERO, _act_code(act), float(slope), True, out_pad, False,
                                          True))
+
+
+class _SpectralScale(torch.autograd.Function):
+    """weight_orig / sigma with (u, v, sigma) as constants of the call: dW = (G - <G, W/sigma> u v^T) / sigma."""
+    @staticmethod
+    def forward(ctx, weight, u, v, sigma):
+        w = _f32c(weight.detach())
+        out = torch.empty_like(w)
+        L.check(L.load().mt_sn_scale_fwd(_ptr(w), _ptr(sigma), _ptr(out), w.numel(), _stream()), "mt_sn_scale_fwd")
+        ctx.save_for_backward(out, u, v, sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weff, u, v, sigma = ctx.saved_tensors
+        lib = L.load()
+        g = _f32c(g)
+        rows, cols = weff.shape[0], weff.numel() // weff.shape[0]
+        nws = int(lib.mt_sn_ws_bytes(rows, cols))
+        ws = torch.empty((nws,), dtype=torch.uint8, device=g.device)
+        dw = torch.empty_like(weff)
+        L.check(lib.mt_sn_scale_bwd(_ptr(g), _ptr(weff), _ptr(u), _ptr(v), _ptr(sigma), _ptr(dw), rows, cols, _ptr(ws),
+                                    nws, _stream()), "mt_sn_scale_bwd")
+        return dw, None, None, None
+
+
+def spectral_norm_weight(weight_orig, u, v, training=True, n_power_iterations=1, eps=1e-12):
+    """torch.nn.utils.spectral_norm's ``compute_weight`` for a Conv2d weight (dim 0 = rows of the matrix view;
+    reference functions.py:113-121): in training mode ``n_power_iterations`` power iterations update the buffers
+    ``u`` [Cout] and ``v`` [Cin*kh*kw] IN PLACE without gradient; returns weight_orig / sigma (fp32 OIHW) whose
+    gradient reaches weight_orig through both the scaling and sigma = u . W v."""
+    _need_hip(weight_orig)
+    lib = L.load()
+    w = _f32c(weight_orig.detach())
+    rows, cols = w.shape[0], w.numel() // w.shape[0]
+    if u.numel() != rows or v.numel() != cols or u.dtype != torch.float32 or v.dtype != torch.float32:
+        raise RuntimeError(f"spectral_norm_weight: u/v of {u.numel()}/{v.numel()} elements for a {rows}x{cols} weight")
+    nws = int(lib.mt_sn_ws_bytes(rows, cols))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=w.device)
+    sigma = torch.empty((1,), dtype=torch.float32, device=w.device)
+    L.check(lib.mt_sn_power_iter(_ptr(w), _ptr(u), _ptr(v), _ptr(sigma), rows, cols,
+                                 int(n_power_iterations) if training else 0, float(eps), _ptr(ws), nws, _stream()),
+            "mt_sn_power_iter")
+    # the iteration continues in place on the next call: the graph keeps this call's vectors (torch clones them too)
+    if weight_orig.requires_grad and torch.is_grad_enabled():
+        u, v = u.clone(), v.clone()
+    return _SpectralScale.apply(weight_orig, u, v, sigma)
 
 
 class _Linear(torch.autograd.Function):

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip_ops as ops
-from .functions import get_activation_layer, get_norm_layer, get_padding_layer, spectral_norm
+from .functions import conv_weight, get_activation_layer, get_norm_layer, get_padding_layer, spectral_norm
 from .norm import AdaptiveInstanceNorm, LayerNorm
 
 
@@ -44,15 +44,14 @@ class ConvBlock(nn.Module):
         self.act = get_activation_layer(activation)
         self.norm = get_norm_layer(norm_layer)
         self.stride, self.padding = stride, padding
-        if sn:
-            spectral_norm(None)
         mods = []
         if self.pad_mode == "reflect":
             mods.append(_Marker("reflection_pad", padding))
         self._ci = len(mods)
         # padding of the holder is 0 when a pad layer precedes it, exactly like the reference
-        mods.append(nn.Conv2d(input_dim, output_dim, kernel_size, stride, 0 if self.pad_mode == "reflect" else padding,
-                              bias=bias))
+        conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, 0 if self.pad_mode == "reflect" else padding,
+                         bias=bias)
+        mods.append(spectral_norm(conv) if sn else conv)
         self._ni = None
         if self.norm is not None:
             self._ni = len(mods)
@@ -64,18 +63,19 @@ class ConvBlock(nn.Module):
     def forward(self, x, res=None, want_stats=False):
         """want_stats: return (conv output, its normalisation statistics) for an external norm layer (AdaIN)."""
         conv = self.block[self._ci]
+        weight = conv_weight(conv, self.training)
         if want_stats:
             assert self.norm is None and self.act is None and res is None
-            return ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+            return ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
                               pad_mode=self.pad_mode, stats=True)
         if self.norm == "instance":
             # statistics come out of the GEMM epilogue; the bias in front of an affine-free InstanceNorm has an
             # identically zero gradient (SURVEY.md Appendix D-4), so none is computed
-            y, sums = ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding,
+            y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
                                  pad_mode=self.pad_mode, stats=True, bias_grad=False)
             return ops.instance_norm_act(y, act=self.act, res=res, sums=sums)
         fused_act = self.act if self.norm is None else None
-        y = ops.conv2d(x, conv.weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
+        y = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
                        act=fused_act)
         if self.norm == "layer":
             y = self.block[self._ni](y, act=self.act)
@@ -91,7 +91,8 @@ class UpsampleBlock(nn.Module):
                  norm_layer=None, activation=None, padding_type=None, sn=False, up_type="transpose"):
         super().__init__()
         if sn:
-            spectral_norm(None)
+            raise NotImplementedError("spectral norm in an UpsampleBlock: no reference model passes sn to a decoder "
+                                      "(only --dis_sn exists, arguments.py:110)")
         self.act = get_activation_layer(activation)
         self.norm = get_norm_layer(norm_layer)
         self.stride, self.padding, self.output_padding = stride, padding, output_padding

@@ -6,6 +6,7 @@ spec objects (the arithmetic is fused into HIP kernels by ``blocks.ConvBlock``),
 process per GPU with RCCL all-reduce (``masterthesis_amd.distributed``) instead of the reference's
 single-process ``nn.DataParallel`` (functions.py:96-106).
 """
+import torch
 import torch.nn as nn
 from torch.nn import init
 from torch.optim import lr_scheduler
@@ -72,14 +73,17 @@ def init_weights(net, init_type="normal", init_gain=0.02):
     def init_func(m):
         classname = m.__class__.__name__
         if hasattr(m, "weight") and classname.find("Conv") == 0:
+            # a spectrally normalised holder keeps its trainable tensor in weight_orig (the reference initialises
+            # the plain ``weight`` attribute, which only aliases weight_orig while the module is still on the CPU)
+            w = m.weight_orig.data if hasattr(m, "weight_orig") else m.weight.data
             if init_type == "normal":
-                init.normal_(m.weight.data, 0.0, init_gain)
+                init.normal_(w, 0.0, init_gain)
             elif init_type == "xavier":
-                init.xavier_normal_(m.weight.data, gain=init_gain)
+                init.xavier_normal_(w, gain=init_gain)
             elif init_type == "kaiming":
-                init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+                init.kaiming_normal_(w, a=0, mode="fan_in")
             elif init_type == "orthogonal":
-                init.orthogonal_(m.weight.data, gain=init_gain)
+                init.orthogonal_(w, gain=init_gain)
             else:
                 raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
             if hasattr(m, "bias") and m.bias is not None:
@@ -97,5 +101,26 @@ def init_net(net, init_type="normal", init_gain=0.02, device="cpu", gpu_ids=()):
     return net
 
 
-def spectral_norm(module, **kw):
-    raise NotImplementedError("--dis_sn (spectral norm) is not implemented in this build (SURVEY.md 8f-4)")
+def spectral_norm(module, name="weight", n_power_iterations=1, eps=1e-12, dim=None):
+    """Reference functions.py:113-121.  ``torch.nn.utils.spectral_norm`` is used for what it registers on the
+    parameter holder -- ``weight_orig`` (Parameter), ``weight_u`` / ``weight_v`` (buffers) and its state-dict hooks,
+    so checkpoints interchange with the reference's -- its forward pre-hook never fires because the holder's own
+    forward is never called: ``conv_weight`` below computes the normalised weight with the HIP kernels."""
+    if dim is None:
+        dim = 1 if isinstance(module, (torch.nn.ConvTranspose1d, torch.nn.ConvTranspose2d, torch.nn.ConvTranspose3d)) else 0
+    if dim != 0:
+        raise NotImplementedError("spectral norm on transposed convolutions is unused by the reference models")
+    module = torch.nn.utils.spectral_norm(module, name, n_power_iterations, eps, dim)
+    module._mt_sn = (int(n_power_iterations), float(eps))
+    return module
+
+
+def conv_weight(conv, training=True):
+    """The weight a conv holder contributes to the forward pass: ``conv.weight``, or for a spectrally normalised
+    holder weight_orig / sigma after this call's power iteration (buffers updated in place, as torch does)."""
+    sn = getattr(conv, "_mt_sn", None)
+    if sn is None:
+        return conv.weight
+    from ... import hip_ops as ops
+    return ops.spectral_norm_weight(conv.weight_orig, conv.weight_u, conv.weight_v, training=training,
+                                    n_power_iterations=sn[0], eps=sn[1])

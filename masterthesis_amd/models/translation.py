@@ -177,14 +177,23 @@ class TranslationModel(Model):
     def backward_discriminator(self, netD, real, fake, c_org):
         """covers the reference's backward_discriminator and backward_multi_scale_discriminator (182-223).
         The fake and the real batch go through the discriminator as ONE concatenated batch (same weights,
-        per-sample independent layers => identical outputs, half the launches, twice the pixels per GEMM)."""
+        per-sample independent layers => identical outputs, half the launches, twice the pixels per GEMM) unless
+        --dis_sn makes the weights depend on the call."""
         n = fake.shape[0]
         loss_d_adv, loss_d_cls = 0, 0
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:209; ms_dis goes via gan_loss)
         ragan = getattr(self.args, "use_ragan", False) and not self.args.ms_dis      # (adain_model.py:206-208)
-        for pred, cls in self._dis_outputs(netD, ops.cat_batch((fake.detach(), real))):
-            pf, pr = torch.split(pred, n, dim=0)
-            cr = cls[n:]
+        if getattr(self.args, "dis_sn", False):
+            # spectral norm runs one power iteration per forward call, so the weights of the two calls differ:
+            # fake first, then real, as the reference does (adain_model.py:184-185, 203-205)
+            outs_f = self._dis_outputs(netD, fake.detach())
+            outs = [(pf, pr, cr) for (pf, _), (pr, cr) in zip(outs_f, self._dis_outputs(netD, real))]
+        else:
+            outs = []
+            for pred, cls in self._dis_outputs(netD, ops.cat_batch((fake.detach(), real))):
+                pf, pr = torch.split(pred, n, dim=0)
+                outs.append((pf, pr, cls[n:]))
+        for pf, pr, cr in outs:
             if ragan:
                 loss_d_adv = loss_d_adv + (self.gan_loss(ops.sub_mean(pr, pf), 1) +
                                            self.gan_loss(ops.sub_mean(pf, pr), 0)) / 2

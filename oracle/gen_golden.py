@@ -257,6 +257,9 @@ def main():
     if want("adain_step_nearest"):
         step_case("adain_step_nearest", "AdaINModel", steps=1, seed=7, num_domains=2, batch_size=1, dim=4,
                   up_type="nearest")
+    if want("adain_step_sn"):
+        # --dis_sn: two steps so the power-iteration vectors carried across calls and steps are pinned too
+        step_case("adain_step_sn", "AdaINModel", steps=2, seed=8, num_domains=2, batch_size=1, dim=4, dis_sn=True)
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)

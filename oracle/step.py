@@ -87,6 +87,10 @@ def hinge_dis(pr, pf):
     return F.relu(1.0 - pr).mean() + F.relu(1.0 + pf).mean()
 
 
+def _is_buffer(key):
+    return key.endswith(".weight_u") or key.endswith(".weight_v")
+
+
 class OracleModel:
     """Functional twin of the reference ``Model``: ``P[net][key]`` leaf tensors + one Adam each."""
 
@@ -95,13 +99,14 @@ class OracleModel:
         self.args = args
         self.dtype = dtype
         self.kind = "adain" if args.model == "AdaINModel" else "base"
-        self.P = {net: {k: torch.as_tensor(v).clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
-                  for net, sd in params.items()}
+        # spectral-norm vectors (weight_u / weight_v) are buffers: no gradient, not optimised
+        self.P = {net: {k: torch.as_tensor(v).clone().to(dtype).requires_grad_(not _is_buffer(k))
+                        for k, v in sd.items()} for net, sd in params.items()}
         self.opt, self.sched = {}, {}
         for net, sd in self.P.items():
             lr = args.lr / 2.5 if net == "content_discriminator" else args.lr      # adain_model.py:65
-            self.opt[net] = torch.optim.Adam(list(sd.values()), lr=lr, betas=(args.beta1, float(args.beta2)),
-                                             weight_decay=args.wd)
+            self.opt[net] = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=lr,
+                                             betas=(args.beta1, float(args.beta2)), weight_decay=args.wd)
             self.sched[net] = torch.optim.lr_scheduler.StepLR(self.opt[net], step_size=args.n_iter_decay, gamma=0.1)
         self.loss = {}
         self.reparam = self.kind == "adain" or args.reparam

@@ -291,6 +291,51 @@ def test_upsample2_nearest(dtype, hip_device):
         _close(xd.grad, xr.grad, dtype, what="upsample2 dx", scale=4.0)
 
 
+@pytest.mark.parametrize("shape", [(8, 3, 3, 3), (64, 32, 3, 3), (100, 37, 4, 4), (1024, 512, 3, 3), (2048, 1024, 4, 4)],
+                         ids=["8x27", "64x288", "100x592", "1024x4608", "2048x16384"])
+def test_spectral_norm_weight(shape, hip_device):
+    """--dis_sn: the power iteration + W / sigma and its gradient against torch.nn.utils.spectral_norm on the CPU
+    (what the reference's ConvBlock wraps its Conv2d in, functions.py:113-121): three training-mode calls (u, v carried
+    in place from call to call), then an eval-mode call."""
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd.models.core.functions import conv_weight, spectral_norm
+    torch.manual_seed(5)
+    Co, Ci, k, _ = shape
+    ref = torch.nn.utils.spectral_norm(torch.nn.Conv2d(Ci, Co, k, bias=False), "weight", 1, 1e-12, 0)
+    with torch.no_grad():
+        ref.weight_orig.normal_(0, 0.02)
+    ours = spectral_norm(torch.nn.Conv2d(Ci, Co, k, bias=False))
+    ours.load_state_dict(ref.state_dict())
+    ours = ours.to(hip_device)
+    x = torch.zeros(1, Ci, k, k)
+    for call in range(3):
+        ref.train()
+        ref(x)                                  # the forward pre-hook runs the power iteration and sets ref.weight
+        w_ref = ref.weight
+        w = conv_weight(ours, training=True)
+        g = _rnd(*shape, seed=30 + call)
+        ref.weight_orig.grad = None
+        w_ref.backward(g)
+        ours.weight_orig.grad = None
+        w.backward(g.to(hip_device))
+        for name, a, b in (("u", ours.weight_u, ref.weight_u), ("v", ours.weight_v, ref.weight_v), ("weight", w, w_ref),
+                           ("grad", ours.weight_orig.grad, ref.weight_orig.grad)):
+            a, b = a.detach().cpu().double(), b.detach().double()
+            rel = ((a - b).norm() / b.norm()).item()
+            assert rel < 2e-5, f"spectral norm {shape} call {call}: {name} rel L2 {rel:.2e}"
+    ref.eval()
+    ref(x)
+    u_before = ours.weight_u.clone()
+    w = conv_weight(ours, training=False)
+    assert torch.equal(u_before, ours.weight_u), "eval mode must not touch the power-iteration vectors"
+    rel = ((w.detach().cpu().double() - ref.weight.detach().double()).norm() / ref.weight.detach().double().norm()).item()
+    assert rel < 2e-5, f"spectral norm {shape} eval: weight rel L2 {rel:.2e}"
+    # frozen discriminator (generator phases): the iteration still runs, no graph is built
+    with ops.frozen(ours):
+        w = conv_weight(ours, training=True)
+    assert not w.requires_grad and not torch.equal(u_before, ours.weight_u)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layout_cat_noise(dtype, hip_device):
     ops = _ops(dtype)

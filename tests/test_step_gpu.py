@@ -47,7 +47,7 @@ def _fp64_truth(z, meta, it_count):
                 opt._orig_step = opt.step
 
             def hooked(_net=net, _opt=opt):
-                seen.append((_net, {k: p.grad.detach().clone() for k, p in O.P[_net].items()}))
+                seen.append((_net, {k: p.grad.detach().clone() for k, p in O.P[_net].items() if p.requires_grad}))
                 return _opt._orig_step()
             opt.step = hooked
         O.update_lr()
@@ -59,7 +59,7 @@ def _fp64_truth(z, meta, it_count):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan",
-                                  "adain_step_hinge", "adain_step_ragan", "adain_step_nearest"])
+                                  "adain_step_hinge", "adain_step_ragan", "adain_step_nearest", "adain_step_sn"])
 def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     z, meta, M, misc = _build(name, tmp_path, precision)
     torch.set_num_threads(8)
@@ -80,6 +80,16 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
         # so its bound only catches gross scale errors; the fp32 run of the same fixture pins the logic)
         grad_tol = [0.25, 0.25, 0.8, 0.5, 0.8, 1.5, 1.5]
     zero_tol = 1e-3 if precision == "fp32" else 5e-2
+    # --dis_sn at these widths: with spectrally normalised weights the adversarial term dominates the generator
+    # gradient, and d(logit)/d(image) is piecewise constant in the LeakyReLU pattern of a 4-channel discriminator.
+    # Measured on the fp64 oracle: a 1e-7 relative perturbation of the input images moves the phase-3 gradient by
+    # 4e-7 or by 9.5e-3 (phase 4: 2e-6 or 0.12) depending on the draw, the reference's own fp32 run sits 1.5e-3 /
+    # 8.5e-2 from fp64, ours 1.7e-6 or 1.6e-2 from run to run (atomics order).  The discriminator phases and
+    # the losses stay at round-off and keep the strict bounds; the generator phases get a gross-error bound.
+    mask_sensitive = name == "adain_step_sn"
+    if mask_sensitive:
+        # (bf16: the same mask sensitivity inside the discriminator phases -- 0.33 measured on D2 -- so only gross bounds)
+        grad_tol = [5e-3, 5e-3, 1e-1, 1e-1, 1e-1, 0.5, 0.5] if precision == "fp32" else [0.6, 0.6, 1.0, 1.0, 1.0, 1.5, 1.5]
     try:
         for it in range(meta["steps"]):
             src = misc.ReplaySource([z[f"rng/{it}/{i}"] for i in range(meta["rng_counts"][it])])
@@ -135,6 +145,8 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
             if precision == "fp32" and it == 0:
                 # after ONE Adam step the update is ~lr*sign(g): compare the parameter deltas
                 for net in M.model:
+                    if mask_sensitive and "discriminator" not in net:
+                        continue        # ~lr*sign(g) updates: a 1 % gradient change flips the sign of ~1 % of them
                     init = sub(z, f"init/{net}")
                     for k, v in M.model[net].state_dict().items():
                         if (net, k) in noise_keys:
