@@ -85,6 +85,48 @@ def test_synthetic_dataset_contract():
     assert a["y1"].sum() == 1 and a["y2"].sum() == 1 and not torch.equal(a["y1"], a["y2"])
 
 
+def test_paired_dataset_contract_on_image_folders(tmp_path):
+    """PairedDataset on a <dataroot>/<mode>/<domain>/*.png tree (reference dataset.py:97-180): bicubic resize to
+    load_size, crop to crop_size, [-1, 1] range, two different domains per item, ``index % len`` wrap-around on the
+    shorter domain, dataset length = the longest domain."""
+    import argparse
+    import numpy as np
+    from PIL import Image
+    from masterthesis_amd.dataset import PairedDataset, SingleDataset
+    rng = np.random.default_rng(0)
+    counts = {"cloudy": 3, "rain": 1, "sunny": 2}
+    for dom, n in counts.items():
+        os.makedirs(tmp_path / "train" / dom)
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)).save(tmp_path / "train" / dom / f"{i}.png")
+        (tmp_path / "train" / dom / "notes.txt").write_text("not an image")
+    args = argparse.Namespace(dataroot=str(tmp_path), mode="train", select_domains=None, num_domains=3, load_size=36,
+                              crop_size=32, no_flip=False)
+    ds = PairedDataset(args, return_paths=True)
+    assert len(ds) == 3 and ds.targets == [0, 1, 2]
+    for idx in range(7):
+        it = ds[idx]
+        assert it["x1"].shape == (3, 32, 32) and it["x2"].dtype == torch.float32
+        assert -1.0 <= it["x1"].min() and it["x1"].max() <= 1.0
+        assert it["y1"].sum() == 1 and it["y2"].sum() == 1 and not torch.equal(it["y1"], it["y2"])
+        for x_path, y in ((it["x1_path"], it["y1"]), (it["x2_path"], it["y2"])):
+            dom = sorted(counts)[int(y.argmax())]
+            assert os.path.basename(os.path.dirname(x_path)) == dom
+            files = ds.dataset[int(y.argmax())]            # (directory order, unsorted like the reference's listdir)
+            assert len(files) == counts[dom] and x_path == files[idx % counts[dom]]
+    # test mode: deterministic centre crop, no flip -> the same tensor twice
+    args_t = argparse.Namespace(**{**vars(args), "mode": "train", "no_flip": True})
+    one = SingleDataset(args_t)
+    one.args = argparse.Namespace(**{**vars(args_t), "mode": "test"})
+    path = one.dataset[1][0]
+    assert torch.equal(one.load_image(path), one.load_image(path))
+    # select_domains restricts the tree; unknown names are refused like the reference's assert
+    sel = PairedDataset(argparse.Namespace(**{**vars(args), "select_domains": ["sunny", "cloudy"], "num_domains": 2}))
+    assert len(sel) == 3 and sel.targets == [0, 1]
+    with pytest.raises(AssertionError):
+        PairedDataset(argparse.Namespace(**{**vars(args), "select_domains": ["sunny", "fog"], "num_domains": 2}))
+
+
 def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
     from masterthesis_amd import models
     z, meta = load_gold("adain_step_d2")
