@@ -172,3 +172,34 @@ def test_short_training_run_bf16_tracks_fp32(tmp_path, hip_device):
     for k in ("total_g", "l1_self_rec", "l1_cc_rec", "d_total"):
         a, b = out["bf16"][1][k], out["fp32"][1][k]
         assert abs(a - b) <= 0.10 * abs(b) + 0.05, f"{k}: bf16 {a} vs fp32 {b} after 80 steps"
+
+
+def test_sampling_path_at_deployment_size(hip_device):
+    """sample.py's forward_random / forward_reference at 540x960 (sample.py:79-91), dim 64: bf16 output within bf16
+    rounding of the fp32 path of the same weights and draws; odd intermediate sizes (135 -> 67 in the style encoder's
+    average pools) and the 2x transposed convolutions of the decoder at 135x240 -> 540x960."""
+    import argparse
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd import models
+    from masterthesis_amd.models.core import misc
+    outs = {}
+    img = torch.rand(1, 3, 540, 960, generator=torch.Generator().manual_seed(3)).to(hip_device) * 2 - 1
+    c = torch.eye(4, device=hip_device)[[2]]
+    z = torch.randn(1, 8, generator=torch.Generator().manual_seed(4)).to(hip_device)
+    for prec in ("fp32", "bf16"):
+        a = argparse.Namespace(mode="test", precision=prec, input_dim=3, dim=64, enc_norm="instance", num_domains=4,
+                               latent_dim=8, up_type="transpose", dec_norm="layer", use_dropout=False, init_type="normal",
+                               init_gain=0.02, resume=None, gpu_ids=[0], batch_size=1, concat=False, reparam=False)
+        torch.manual_seed(0)
+        M = models.AdaINModel(a)
+        M.initialize()
+        for net in M.model:
+            M.model[net].eval()             # no content noise: the two precisions see the same function
+        with torch.no_grad():
+            r, _, _ = M.forward_random(img, z, c)
+            f, _, _ = M.forward_reference(img, img.flip(3), c)
+        outs[prec] = (ops.to_nchw_f32(r), ops.to_nchw_f32(f))
+    for a, b in zip(outs["bf16"], outs["fp32"]):
+        assert a.shape == (1, 3, 540, 960) and torch.isfinite(a).all()
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 3e-2, f"bf16 sampling output differs from fp32 by rel L2 {rel:.2e}"
