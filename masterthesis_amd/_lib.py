@@ -109,6 +109,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C masterthesis_amd/csrc`). There is no fallback backend.")
+    # torch first: its bundled HIP runtime must be the one already in the process when the library's
+    # libamdhip64.so.7 dependency is resolved -- loading the library before torch pulls in /opt/rocm's copy as a
+    # second runtime, which then finds no device once torch's has claimed it
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
