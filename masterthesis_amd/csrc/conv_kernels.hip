@@ -8,6 +8,7 @@
 // Replaces: nn.ReflectionPad2d + nn.Conv2d (reference blocks.py:29-35), nn.ConvTranspose2d
 // (blocks.py:73) and their autograd backward.
 #include "mt_common.h"
+#include <stdlib.h>
 #include "conv_params.h"
 #include <type_traits>
 
@@ -354,6 +355,13 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
       n512 += cdiv(p.ph[i].M, 512) * (p.CoRows / 128);
     }
     if (ok && n512 >= 224 && (n512 % 256 == 0 || n512 >= 768)) { PT = 512; WT = 128; }
+  }
+  // latency-bound small launches (e.g. the ring GEMM of the stride-1 data gradient, 68 blocks): 64-channel tiles
+  // double the number of blocks that share the serial k loop (-0.3 ms per step)
+  if (WT == 128 && PT == 128 && !p.raw && p.CoRows % 128 == 0) {
+    int t128 = 0;
+    for (int i = 0; i < p.nphase; i++) t128 += cdiv(p.ph[i].M, PT) * cdiv(p.CoRows, 128);
+    if (t128 <= 128) WT = 64;
   }
   int total = 0;
   for (int i = 0; i < p.nphase; i++) {
