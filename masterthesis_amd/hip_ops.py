@@ -389,6 +389,9 @@ class _Conv(torch.autograd.Function):
         ctx.desc = desc
         ctx.owner = owner
         ctx.bias_owner = bias
+        # the statistics output never carries a gradient: without this autograd materialises a zero tensor for it
+        # on every backward call (57 fill kernels per step)
+        ctx.set_materialize_grads(False)
         ctx.has_bias = bias is not None and bias_grad
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         if want_stats:
@@ -401,6 +404,8 @@ class _Conv(torch.autograd.Function):
         lib = L.load()
         x, weight, y = ctx.saved_tensors
         desc = ctx.desc
+        if dy is None:
+            return None, None, None, None
         dy = canon(dy)
         if desc.act != L.ACT_NONE:
             dz = new_act(*dy.shape, dy.dtype, dy.device)
