@@ -260,6 +260,11 @@ def main():
     if want("adain_step_sn"):
         # --dis_sn: two steps so the power-iteration vectors carried across calls and steps are pinned too
         step_case("adain_step_sn", "AdaINModel", steps=2, seed=8, num_domains=2, batch_size=1, dim=4, dis_sn=True)
+    if want("adain_step_dc"):
+        # --use_dis_content: iteration 0 is a full step with the content-adversarial generator term, iteration 1 only
+        # updates the content discriminator (d_iter gating); 224x224 because Dc needs a >= 53x53 content map
+        step_case("adain_step_dc", "AdaINModel", steps=2, seed=9, num_domains=2, batch_size=1, dim=4, crop_size=224,
+                  use_dis_content=True)
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)
