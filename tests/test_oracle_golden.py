@@ -58,7 +58,9 @@ def test_network_forward_matches_reference(tag):
         outs = NET_FNS[tag](P, inp, rng)
     assert len(outs) == case["n_out"]
     for i, o in enumerate(outs):
-        close(o, z[f"{tag}/out/{i}"], what=f"{tag} out{i}")
+        # relative to the output's own range (no absolute slack: N(0, 0.02)-initialised stacks without normalisation
+        # produce outputs of 1e-4 .. 1e-8, where an absolute tolerance would pass anything)
+        close(o, z[f"{tag}/out/{i}"], rtol=1e-4, atol=0.0, what=f"{tag} out{i}")
 
 
 def _run_step_case(name):
@@ -99,10 +101,14 @@ def test_training_step_matches_reference(name):
             assert abs(M.loss[k] - v) <= 1e-5 + 2e-4 * abs(v), f"{name} it{it} loss {k}: {M.loss[k]} vs {v}"
         assert [n for n, _ in seen] == meta["grad_nets"][it]
         for j, (net, g) in enumerate(seen):
+            # absolute slack relative to the largest gradient of THIS network (discriminator gradients of the
+            # N(0, 0.02)-initialised fixtures are 1e-6 .. 1e-4: a fixed atol would not test them)
+            net_max = max([float(np.abs(z[f"grad/{it}/{j}/{net}/{k}"]).max()) for k in g
+                           if f"grad/{it}/{j}/{net}/{k}" in z.files] or [0.0])
             for k, v in g.items():
                 full, cs = f"grad/{it}/{j}/{net}/{k}", f"gradsum/{it}/{j}/{net}/{k}"
                 if full in z.files:
-                    close(v, z[full], rtol=2e-3, atol=1e-7, what=f"{name} it{it} step{j} {net}.{k} grad")
+                    close(v, z[full], rtol=2e-3, atol=1e-6 * net_max, what=f"{name} it{it} step{j} {net}.{k} grad")
                 elif cs in z.files:
                     np.testing.assert_allclose(checksum(v)[1:], z[cs][1:], rtol=2e-3, err_msg=f"{cs}")
         for net, sd in M.P.items():

@@ -230,3 +230,71 @@ def test_every_network_forward_matches_reference(tag, precision, tol, hip_device
         assert o.shape == ref.shape, (tag, i, o.shape, ref.shape)
         err = ((o - ref).abs().max() / ref.abs().max()).item()
         assert err < tol, f"{tag} output {i} ({precision}): max error {err:.2e} of the output range"
+
+
+@pytest.mark.parametrize("tag", list(NET_CASES))
+def test_every_network_backward_matches_oracle(tag, hip_device):
+    """Parameter and input gradients of every network class (fp32) against torch autograd through the CPU oracle's
+    restatement (itself pinned forward by the recorded reference outputs of the same fixture), float64, for a random
+    cotangent on every output.  This is what covers the backward of the networks no step fixture trains at full width:
+    the weight-shared three-scale MultiScaleDiscriminator, and eval-mode variants of the rest."""
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd.models.core import misc, networks as N
+    from oracle import nets as onets
+    ops.set_compute_dtype(torch.float32)
+    z, meta = load_gold("nets_forward")
+    case = [c for c in meta["cases"] if c["tag"] == tag][0]
+    oracle_fn = {
+        "Ec": lambda P, i, r: [onets.content_encoder(P, i["x"], None)],
+        "Es": lambda P, i, r: list(onets.style_encoder_reparam(P, i["x"], i["c"], r[0])),
+        "AdaINDec": lambda P, i, r: [onets.adain_decoder(P, i["x"], i["z"], i["c"])],
+        "D": lambda P, i, r: list(onets.discriminator(P, i["x"])),
+        "MsD": lambda P, i, r: [t for pair in onets.multi_scale_discriminator(P, i["x"]) for t in pair],
+        "Dc": lambda P, i, r: [onets.content_discriminator(P, i["x"])],
+        "EsPlain": lambda P, i, r: [onets.style_encoder_plain(P, i["x"], i["c"])],
+        "DecConcat": lambda P, i, r: [onets.decoder_concat(P, i["x"], i["z"], i["c"])],
+    }[tag]
+    rng = [torch.from_numpy(z[f"{tag}/rng/{i}"]) for i in range(case["n_rng"])]
+    # ---- float64 truth
+    P64 = {k: v.double().requires_grad_(True) for k, v in sub(z, f"{tag}/P").items()}
+    in64 = {k: v.double().requires_grad_(k in ("x", "z")) for k, v in sub(z, f"{tag}/in").items()}
+    outs64 = oracle_fn(P64, in64, [r.double() for r in rng])
+    g = torch.Generator().manual_seed(11)
+    cot = [torch.randn(o.shape, generator=g) for o in outs64]
+    sum((o * c.double()).sum() for o, c in zip(outs64, cot)).backward()
+    # ---- product
+    make, call = NET_CASES[tag]
+    net = make(N)
+    net.load_state_dict(sub(z, f"{tag}/P"))
+    net = net.to(hip_device).eval()
+    inp = {k: v.to(hip_device).requires_grad_(k in ("x", "z")) for k, v in sub(z, f"{tag}/in").items()}
+    misc.set_random_source(misc.ReplaySource([z[f"{tag}/rng/{i}"] for i in range(case["n_rng"])]))
+    try:
+        res = call(net, inp)
+    finally:
+        misc.set_random_source(None)
+    res = res if isinstance(res, (tuple, list)) else (res,)
+    flat = []
+    for r in res:
+        flat += list(r) if isinstance(r, (tuple, list)) else [r]
+    # (the product's activations are NHWC-padded views: feed the cotangent through backward() instead of a dot product)
+    torch.autograd.backward(flat, [ops.canon(c.to(hip_device)) if c.dim() == 4 else c.to(hip_device) for c in cot])
+    gmax = max(p.grad.abs().max().item() for p in P64.values() if p.grad is not None)
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        ref = P64[k].grad
+        if ref is None or ref.abs().max().item() < 1e-6 * gmax:
+            continue                    # e.g. the bias in front of an affine-free InstanceNorm (true gradient 0)
+        assert p.grad is not None, f"{tag}: no gradient for {k}"
+        d = (p.grad.detach().cpu().double() - ref)
+        num += (d ** 2).sum().item()
+        den += (ref ** 2).sum().item()
+        assert d.norm().item() <= 2e-2 * ref.norm().item() + 1e-5 * gmax, \
+            f"{tag}.{k}: gradient rel L2 {(d.norm() / ref.norm()).item():.2e}"
+    assert (num / den) ** 0.5 < 2e-3, f"{tag}: parameter gradient rel L2 {(num / den) ** 0.5:.2e}"
+    for k in ("x", "z"):
+        if k in inp and in64[k].grad is not None:
+            got = inp[k].grad
+            got = (ops.to_nchw_f32(got) if got.dim() == 4 else got.float()).cpu().double()
+            rel = ((got - in64[k].grad).norm() / in64[k].grad.norm()).item()
+            assert rel < 2e-3, f"{tag}: input gradient d{k} rel L2 {rel:.2e}"
