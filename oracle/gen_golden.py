@@ -220,6 +220,11 @@ def nets_case(name="nets_forward", seed=3):
     zc2 = rnd(2, 32, 16, 16)
     add("DecConcat", N.DecoderConcat(3, dim=32, num_domains=4, latent_dim=8), {"x": zc2, "z": z, "c": c},
         lambda n: n(zc2, z, c))
+    # BaseModel without --concat: forward only (the reference's training step raises there on torch >= 2: in-place
+    # `out += residual` on a ReLU output, blocks.py:190,207)
+    zc3 = rnd(2, 32, 16, 16)
+    add("DecPlain", N.Decoder(3, dim=32, num_domains=4, latent_dim=8), {"x": zc3, "z": z, "c": c},
+        lambda n: n(zc3, z, c))
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)

@@ -45,7 +45,8 @@ def test_network_keys_of_optional_networks():
     for tag, net in [("MsD", N.MultiScaleDiscriminator(3, dim=2, num_domains=4)),
                      ("Dc", N.ContentDiscriminator(dim=8, num_domains=4)),
                      ("EsPlain", N.StyleEncoder(3, output_dim=8, dim=8, num_domains=4, activation="lrelu")),
-                     ("DecConcat", N.DecoderConcat(3, dim=32, num_domains=4, latent_dim=8))]:
+                     ("DecConcat", N.DecoderConcat(3, dim=32, num_domains=4, latent_dim=8)),
+                     ("DecPlain", N.Decoder(3, dim=32, num_domains=4, latent_dim=8))]:
         ref = sub(z, f"{tag}/P")
         assert list(net.state_dict().keys()) == list(ref.keys()), tag
         net.load_state_dict(ref)

@@ -45,6 +45,7 @@ NET_FNS = {
     "Dc": lambda P, i, r: [nets.content_discriminator(P, i["x"])],
     "EsPlain": lambda P, i, r: [nets.style_encoder_plain(P, i["x"], i["c"])],
     "DecConcat": lambda P, i, r: [nets.decoder_concat(P, i["x"], i["z"], i["c"])],
+    "DecPlain": lambda P, i, r: [nets.decoder_plain(P, i["x"], i["z"], i["c"])],
 }
 
 

@@ -195,6 +195,7 @@ NET_CASES = {
                 lambda n, i: n(i["x"], i["c"])),
     "DecConcat": (lambda N: N.DecoderConcat(3, dim=32, num_domains=4, latent_dim=8),
                   lambda n, i: n(i["x"], i["z"], i["c"])),
+    "DecPlain": (lambda N: N.Decoder(3, dim=32, num_domains=4, latent_dim=8), lambda n, i: n(i["x"], i["z"], i["c"])),
 }
 
 
@@ -254,6 +255,7 @@ def test_every_network_backward_matches_oracle(tag, hip_device):
         "Dc": lambda P, i, r: [onets.content_discriminator(P, i["x"])],
         "EsPlain": lambda P, i, r: [onets.style_encoder_plain(P, i["x"], i["c"])],
         "DecConcat": lambda P, i, r: [onets.decoder_concat(P, i["x"], i["z"], i["c"])],
+        "DecPlain": lambda P, i, r: [onets.decoder_plain(P, i["x"], i["z"], i["c"])],
     }[tag]
     rng = [torch.from_numpy(z[f"{tag}/rng/{i}"]) for i in range(case["n_rng"])]
     # ---- float64 truth
