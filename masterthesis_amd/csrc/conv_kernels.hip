@@ -502,6 +502,7 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   MT_CHECK(taps <= MT_MAX_TAPS, "igemm: %d taps > %d", taps, MT_MAX_TAPS);
   IgemmParams q = p;
   q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
+  q.korder = 1;       // ping-pong kernels walk K channel-slice-major (see conv_pipe_kernel.hip: L2-resident re-reads)
   if (thin_dot_ok(q)) {
     if (q.ph[0].M == 0) return 0;
     if (dtype == MT_BF16) hipLaunchKernelGGL((thin_dot_kernel<true>), dim3(q.ph[0].M), dim3(256), 0, s, q);

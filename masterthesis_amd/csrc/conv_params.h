@@ -47,6 +47,7 @@ struct IgemmParams {
   int pad_mode;
   int act;
   float slope;
+  int korder;         // ping-pong kernel: 1 = walk K channel-slice-major (all taps of a 32-channel slice, then the next slice)
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements
                       // whatever the storage type); mt_launch_splitk_finish sums the slabs
   short dh[MT_MAX_TAPS];

@@ -138,6 +138,11 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
     wo32[i] = (rs < WT && row < p.CoRows) ? ((unsigned)row * (unsigned)ph.wrow + (unsigned)c) * 16u : OOB;
   }
   int tap_s = 0, cqb = 0;       // wave-uniform: filter tap and first chunk inside it of the NEXT stage to issue
+  // K order.  Tap-major (the pack order): a tile re-reads its ~200 KB input patch once per tap, 8 k-steps apart --
+  // with 32 tiles per XCD that is 6 MB against 4 MB of L2, so most re-reads go out to the fabric.  Slice-major: the
+  // taps of one 32-channel slice back to back (25 KB per tile), every input byte leaves HBM/MALL once.
+  const bool slice_major = p.korder != 0;
+  unsigned wk = 0;              // byte offset of the next stage's chunk group inside a weight row
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)ph_w, 0, ph.w_bytes, 0x00020000);
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   auto issue_piece = [&](int slot, int j) {
     char* base = lds0 + slot * (STAGE * 16);
     if (j < NWL) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j], 0, 0, 0);
-      wo32[j] += 64u;
+      // (an OOB-marked row plus a k offset stays >= 2 GiB: the pack is < 2 GiB, checked by the host)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j] + wk, 0, 0, 0);
     } else {
       const int i = j - NWL;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(base + WR * 64 + (wvu + NW * i) * 1024), 16, xo32[i], 0, 0,
@@ -165,11 +170,22 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   // table entries of the stage after the one just issued (scalar tap / chunk bookkeeping, two LDS reads)
   unsigned tq[4];
   auto next_lookup = [&]() {
-    cqb += 4;
-    const bool wrap = cqb >= p.cpc;
-    cqb = wrap ? 0 : cqb;
-    tap_s = wrap ? tap_s + 1 : tap_s;
-    tap_s = tap_s > ph_ntaps ? ph_ntaps : tap_s;
+    if (slice_major) {
+      tap_s += 1;
+      const bool wrap = tap_s >= ph_ntaps;
+      cqb = wrap ? cqb + 4 : cqb;
+      tap_s = wrap ? 0 : tap_s;
+      tap_s = cqb >= p.cpc ? ph_ntaps : tap_s;       // past the end of K: the all-OOB table row
+      cqb = cqb >= p.cpc ? p.cpc : cqb;
+      wk = (unsigned)((tap_s * p.cpc + cqb) * 16);
+    } else {
+      cqb += 4;
+      const bool wrap = cqb >= p.cpc;
+      cqb = wrap ? 0 : cqb;
+      tap_s = wrap ? tap_s + 1 : tap_s;
+      tap_s = tap_s > ph_ntaps ? ph_ntaps : tap_s;
+      wk += 64u;
+    }
 #pragma unroll
     for (int i = 0; i < NXL; i++) tq[i] = sT[tap_s * PT + prow[i]];
   };
