@@ -47,6 +47,8 @@ struct IgemmParams {
   int pad_mode;
   int act;
   float slope;
+  int interleave;     // multi-phase launches whose phases have equal block counts: block b -> (phase b % nphase, tile b / nphase),
+                      // so the sub-pixel phases of one input region run side by side and share it in L2
   int korder;         // ping-pong kernel: 1 = walk K channel-slice-major (all taps of a 32-channel slice, then the next slice)
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements
                       // whatever the storage type); mt_launch_splitk_finish sums the slabs

@@ -74,7 +74,12 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   const int nWT = (p.CoRows + WT - 1) / WT;
   int wg = xcd_remap(blockIdx.x, gridDim.x);
   int phi = 0;
-  for (int i = 1; i < p.nphase; i++) phi = (wg >= p.ph[i].blk0) ? i : phi;
+  if (p.interleave) {
+    phi = wg % p.nphase;
+    wg = wg / p.nphase + p.ph[phi].blk0;
+  } else {
+    for (int i = 1; i < p.nphase; i++) phi = (wg >= p.ph[i].blk0) ? i : phi;
+  }
   const IgemmPhase& ph = p.ph[phi];
   const int ph_ntaps = ph.ntaps, ph_Ho = ph.Ho, ph_Wo = ph.Wo, ph_M = ph.M;
   const int ph_nchunks = ph_ntaps * p.cpc;
