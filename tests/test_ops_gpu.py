@@ -482,6 +482,16 @@ def test_pack_multi_matches_single(hip_device):
         (L.MT_BF16, 0, 8, 40, 3, 2, 1, L.PAD_REFLECT, L.PACK_BWD_DATA),      # 4 sub-pixel phase images
         (L.MT_F32, 1, 24, 8, 3, 2, 1, L.PAD_ZERO, L.PACK_FWD),               # transposed conv, phased
         (L.MT_F32, 0, 3, 8, 7, 1, 3, L.PAD_REFLECT, L.PACK_BWD_DATA),
+        # images of >= 64 K elements take the LDS-tiled modes of the batched kernel
+        (L.MT_BF16, 0, 128, 96, 3, 1, 1, L.PAD_REFLECT, L.PACK_FWD),          # mode 1 (taps contiguous per row)
+        (L.MT_BF16, 0, 128, 96, 3, 1, 1, L.PAD_REFLECT, L.PACK_BWD_DATA),     # mode 2, ring image with repeated taps
+        (L.MT_BF16, 0, 100, 120, 3, 1, 1, L.PAD_REFLECT, L.PACK_FWD),         # ragged: 100 -> 104 padded columns
+        (L.MT_F32, 0, 100, 120, 3, 1, 1, L.PAD_ZERO, L.PACK_BWD_DATA),        # ragged rows, fp32 image
+        (L.MT_BF16, 0, 128, 256, 3, 2, 1, L.PAD_REFLECT, L.PACK_BWD_DATA),    # 4 sub-pixel phase images (1-4 taps)
+        (L.MT_BF16, 1, 256, 128, 3, 2, 1, L.PAD_ZERO, L.PACK_FWD),            # IOHW weights, phased forward images
+        (L.MT_BF16, 0, 64, 128, 4, 2, 1, L.PAD_ZERO, L.PACK_FWD),             # 16 taps
+        (L.MT_BF16, 0, 64, 128, 4, 2, 1, L.PAD_ZERO, L.PACK_BWD_DATA),
+        (L.MT_BF16, 0, 32, 64, 7, 1, 3, L.PAD_REFLECT, L.PACK_FWD),           # 49 taps
     ]
     descs, ws, singles, multis, whichs = [], [], [], [], []
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -501,7 +511,7 @@ def test_pack_multi_matches_single(hip_device):
                                          (C.c_void_p * n)(*[w.data_ptr() for w in ws]),
                                          (C.c_void_p * n)(*[b.data_ptr() for b in multis]), host, C.byref(ne),
                                          C.byref(nb)), "build")
-    assert ne.value == 1 + 1 + 4 + 4 + 1
+    assert ne.value == (1 + 1 + 4 + 4 + 1) + (1 + 1 + 1 + 1 + 4 + 4 + 1 + 4 + 1)
     dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(hip_device)
     L.check(lib.mt_conv_pack_multi_run(C.c_void_p(dev.data_ptr()), ne.value, nb.value, stream), "run")
     torch.cuda.synchronize()
