@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const u32x4* __res
       if (res) v += r[e];
       f[e] = v;
     }
-    y[i] = Elem<BF16>::pack(f);
+    __builtin_nontemporal_store(Elem<BF16>::pack(f), &y[i]);      // streaming: written once, read by the next kernel
   }
 }
 static inline void ew_geometry(int HW, int cchunks, int N, int* threads, int* ppb, dim3* grid) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const u32x4* __rest
       const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
       f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
     }
-    dx[i] = Elem<BF16>::pack(f);
+    __builtin_nontemporal_store(Elem<BF16>::pack(f), &dx[i]);
   }
 }
 extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
