@@ -146,6 +146,7 @@ class TranslationModel(Model):
     # ---- PHASE 1-2 ----------------------------------------------------------------------------------
     @ops.step_scope
     def update_discriminator(self, img, c_org):
+        self._finish_deferred()
         B = self.args.batch_size
         cls_a, cls_b = torch.split(c_org, B, dim=0)
         with torch.no_grad():
@@ -166,7 +167,19 @@ class TranslationModel(Model):
             self.backward_discriminator(self.model[name], img, fake, c_org)
             opt = self.optimizer[name]
             pending.append((opt, self.reducer.reduce([opt.flat_grad()])[0]))
-        for opt, h in pending:
+        # discriminator1 is needed by phase 3; discriminator2 only by phase 4, so with a live exchange its wait + Adam
+        # step move in front of phase 4 and its all-reduce also hides behind the whole of phase 3
+        (opt1, h1), d2 = pending
+        self.reducer.wait(h1)
+        opt1.step()
+        if self.reducer.enabled:
+            self._deferred_steps = [d2]
+        else:
+            self._finish_deferred([d2])
+
+    def _finish_deferred(self, items=None):
+        items = self.__dict__.pop("_deferred_steps", []) if items is None else items
+        for opt, h in items:
             self.reducer.wait(h)
             opt.step()
 
@@ -215,6 +228,7 @@ class TranslationModel(Model):
             self.optimizer[n].zero_grad()
         self.backward_generator(img, c_org)
         self._reduce_and_step(("content_encoder", "style_encoder", "decoder"))
+        self._finish_deferred()                 # discriminator2's step (deferred by update_discriminator)
         for n in ("content_encoder", "decoder"):
             self.optimizer[n].zero_grad()
         self.backward_decoder_random(img, c_org)
@@ -324,4 +338,7 @@ class TranslationModel(Model):
             self.update_content_discriminator(self.img, self.c_org)
             return
         self.update_discriminator(self.img, self.c_org)
-        self.update_generator(self.img, self.c_org)
+        try:
+            self.update_generator(self.img, self.c_org)
+        finally:
+            self._finish_deferred()             # (no-op unless update_generator raised before phase 4)
