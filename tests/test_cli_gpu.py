@@ -32,6 +32,36 @@ def test_train_cli_checkpoint_resume(tmp_path, hip_device):
     assert "model_7.ckpt" in os.listdir(ck)
 
 
+@pytest.mark.parametrize("flags", [["--dis_sn"], ["--gan_mode", "hinge", "--up_type", "nearest"],
+                                   ["--gan_mode", "lsgan", "--use_ragan"], ["--ms_dis", "--crop_size", "256"],
+                                   ["--use_dis_content", "--crop_size", "224", "--d_iter", "2"]],
+                         ids=["dis_sn", "hinge_nearest", "lsgan_ragan", "ms_dis", "dis_content"])
+def test_train_cli_optional_flags(flags, tmp_path, hip_device):
+    """Every optional flag of SURVEY 8f-4 through the command line: three iterations in bf16, a checkpoint, a resume;
+    for --dis_sn the checkpoint carries the reference's spectral-norm keys and the power-iteration vectors move."""
+    from masterthesis_amd import train
+    common = ["--model", "AdaINModel", "--dataset", "SyntheticDataset", "--exp_dir", str(tmp_path), "--name", "run",
+              "--batch_size", "1", "--num_domains", "2", "--dim", "8", "--crop_size", "64", "--num_workers", "0",
+              "--synthetic_len", "4", "--print_freq", "1", "--save_freq", "2", "--display_freq", "100",
+              "--precision", "bf16"] + flags
+    train.main(common + ["--n_iters", "3", "--max_iter", "3"])
+    ck = os.path.join(str(tmp_path), "run", "checkpoints")
+    sd0, sd = torch.load(os.path.join(ck, "model_0.ckpt")), torch.load(os.path.join(ck, "model_2.ckpt"))
+    assert all(torch.isfinite(v).all() for net in sd.values() for v in net.values() if v.is_floating_point())
+    if "--dis_sn" in flags:
+        keys = set(sd["discriminator1"])
+        assert {"model.0.block.1.weight_orig", "model.0.block.1.weight_u", "model.0.block.1.weight_v"} <= keys
+        assert "model.0.block.1.weight" not in keys
+        assert not torch.equal(sd0["discriminator1"]["model.0.block.1.weight_u"],
+                               sd["discriminator1"]["model.0.block.1.weight_u"])
+    if "--use_dis_content" in flags:
+        assert "content_discriminator" in sd
+        assert not torch.equal(sd0["content_discriminator"]["model.4.weight"], sd["content_discriminator"]["model.4.weight"])
+    train.main(common + ["--n_iters", "5", "--max_iter", "5", "--resume", os.path.join(ck, "model_2.ckpt"),
+                         "--resume_opt", os.path.join(ck, "opt_2.ckpt"), "--last_iter", "2"])
+    assert "model_4.ckpt" in os.listdir(ck)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_inference_surface(precision, tmp_path, hip_device):
     import argparse
