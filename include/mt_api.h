@@ -145,6 +145,12 @@ int mt_add(int dtype, const void* a, const void* b, void* y, size_t n, mt_stream
 /* ... or generated on device: Philox4x32-10 + Box-Muller, N(0,1), counter = element index. */
 int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t seed,
                           uint64_t offset, mt_stream_t s);
+/* nn.Dropout(0.5) (--use_dropout; blocks.py:133-134, 153-165, 192-207): mask ~ Bernoulli(keep) in the activation layout
+ * [npix][Cp] (pad channels 0; Philox4x32-10, counter = element index), and y = a * b * scale (forward: x * mask / keep,
+ * backward: dy * mask / keep). */
+int mt_bernoulli_mask(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed, uint64_t offset,
+                      mt_stream_t s);
+int mt_mul_scale(int dtype, const void* a, const void* b, void* y, size_t n, float scale, mt_stream_t s);
 int mt_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
 /* nn.Upsample(scale_factor=2, mode='nearest') (blocks.py:75, --up_type nearest).  H, W: size of the UPSAMPLED map.

@@ -64,6 +64,8 @@ SIGNATURES = {
     "mt_act_bwd": (_i, [_i, _p, _p, _p, _z, _i, _f, _p]),
     "mt_add": (_i, [_i, _p, _p, _p, _z, _p]),
     "mt_gaussian_noise_add": (_i, [_i, _p, _p, _z, _u64, _u64, _p]),
+    "mt_bernoulli_mask": (_i, [_i, _p, _z, _i, _i, _f, _u64, _u64, _p]),
+    "mt_mul_scale": (_i, [_i, _p, _p, _p, _z, _f, _p]),
     "mt_avgpool2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),

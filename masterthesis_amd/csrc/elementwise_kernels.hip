@@ -142,6 +142,61 @@ extern "C" int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n
   return 0;
 }
 
+// ---- dropout (nn.Dropout(0.5) at the end of the decoders' residual branches, --use_dropout; blocks.py:133-134,153-165,
+// 192-207): y = x * mask / keep with mask ~ Bernoulli(keep).  The mask is a tensor in the activation layout (given in
+// parity mode, else drawn here: Philox4x32-10, counter = element index), the same product serves the backward pass.
+template <bool BF16>
+__global__ void bernoulli_mask_kernel(u32x4* __restrict__ mask, long nchunks, int cchunks, int C, float keep,
+                                      unsigned long long seed, unsigned long long offset) {
+  constexpr int V = Elem<BF16>::V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cchunks) * V;
+    float f[V];
+#pragma unroll
+    for (int h = 0; h < V / 4; h++) {
+      unsigned r[4];
+      philox4(offset + (unsigned long long)i * (V / 4) + h, seed, r);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        f[h * 4 + e] = (c0 + h * 4 + e < C && (float)r[e] * 2.3283064365386963e-10f < keep) ? 1.f : 0.f;   // pad channels stay 0
+    }
+    mask[i] = Elem<BF16>::pack(f);
+  }
+}
+extern "C" int mt_bernoulli_mask(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed,
+                                 uint64_t offset, mt_stream_t s) {
+  long nc;
+  if (check_n(dtype, npix * (size_t)Cp, &nc)) return 1;
+  if (nc == 0) return 0;
+  const int cchunks = Cp / (dtype == MT_BF16 ? 8 : 4);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((bernoulli_mask_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset);
+  else hipLaunchKernelGGL((bernoulli_mask_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+template <bool BF16>
+__global__ void mul_scale_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ y,
+                                 long nchunks, float scale) {
+  constexpr int V = Elem<BF16>::V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float f[V], g[V];
+    Elem<BF16>::unpack(a[i], f);
+    Elem<BF16>::unpack(b[i], g);
+#pragma unroll
+    for (int e = 0; e < V; e++) f[e] = f[e] * g[e] * scale;
+    y[i] = Elem<BF16>::pack(f);
+  }
+}
+extern "C" int mt_mul_scale(int dtype, const void* a, const void* b, void* y, size_t n, float scale, mt_stream_t s) {
+  long nc;
+  if (check_n(dtype, n, &nc)) return 1;
+  if (nc == 0) return 0;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((mul_scale_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)a, (const u32x4*)b, (u32x4*)y, nc, scale);
+  else hipLaunchKernelGGL((mul_scale_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)a, (const u32x4*)b, (u32x4*)y, nc, scale);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- pooling ------------------------------------------------------------------------------
 // AvgPool2d(2,2): H, W of the INPUT (floor semantics for odd sizes)
 // `scale` = 0.25 for the average pool and its adjoint; with scale = 1 the two branches are the adjoint pair of

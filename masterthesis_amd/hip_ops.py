@@ -715,6 +715,42 @@ class _NoiseAdd(torch.autograd.Function):
         return dy, None, None
 
 
+class _MulScale(torch.autograd.Function):
+    """x * mask * scale with a constant mask (dropout): the same product is the gradient."""
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x = canon(x)
+        y = new_act(*x.shape, x.dtype, x.device)
+        L.check(L.load().mt_mul_scale(_mt(x.dtype), _ptr(x), _ptr(mask), _ptr(y), _numel_padded(x), scale, _stream()),
+                "mt_mul_scale")
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = canon(dy)
+        dx = new_act(*dy.shape, dy.dtype, dy.device)
+        L.check(L.load().mt_mul_scale(_mt(dy.dtype), _ptr(dy), _ptr(mask), _ptr(dx), _numel_padded(dy), ctx.scale,
+                                      _stream()), "mt_mul_scale")
+        return dx, None, None
+
+
+def bernoulli_mask(shape, keep, seed, offset, device):
+    """0/1 mask ~ Bernoulli(keep) as a canonical activation (Philox counter kernel)."""
+    N, Cc, H, W = shape
+    m = new_act(N, Cc, H, W, compute_dtype(), device)
+    L.check(L.load().mt_bernoulli_mask(_mt(m.dtype), _ptr(m), N * H * W, Cc, padc(Cc), float(keep), seed, offset,
+                                       _stream()), "mt_bernoulli_mask")
+    return m
+
+
+def dropout(x, mask, p=0.5):
+    """nn.Dropout(p) in training mode with the given keep-mask (canonical 0/1 activation): x * mask / (1 - p)."""
+    return _MulScale.apply(x, canon(mask), 1.0 / (1.0 - p))
+
+
 def gaussian_noise_add(x, seed, offset):
     """x + N(0,1) drawn on device (Philox4x32-10, counter = element index + offset)."""
     if padc(x.shape[1]) != x.shape[1]:

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from ... import hip_ops as ops
 from .functions import conv_weight, get_activation_layer, get_norm_layer, get_padding_layer, spectral_norm
+from .misc import Dropout
 from .norm import AdaptiveInstanceNorm, LayerNorm
 
 
@@ -163,14 +164,16 @@ class ResnetBlock(nn.Module):
     def __init__(self, input_dim, output_dim, dropout=False, norm_layer="instance", padding_type="reflect",
                  activation="relu"):
         super().__init__()
+        mods = [ConvBlock(input_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer,
+                          activation=activation),
+                ConvBlock(output_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer)]
         if dropout:
-            raise NotImplementedError("--use_dropout is not implemented (off by default)")
-        self.model = nn.Sequential(
-            ConvBlock(input_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer,
-                      activation=activation),
-            ConvBlock(output_dim, output_dim, 3, 1, 1, padding_type=padding_type, norm_layer=norm_layer))
+            mods.append(Dropout(0.5))           # (index 2 of the Sequential, like the reference's nn.Dropout)
+        self.model = nn.Sequential(*mods)
 
     def forward(self, x):
+        if len(self.model) > 2 and self.training:
+            return ops.add(self.model[2](self.model[1](self.model[0](x))), x)
         return self.model[1](self.model[0](x), res=x)
 
 
@@ -179,19 +182,19 @@ class AdaINResnetBlock(nn.Module):
 
     def __init__(self, input_dim, output_dim, dropout=False, style_dim=256, padding_type="reflect", activation="relu"):
         super().__init__()
-        if dropout:
-            raise NotImplementedError("--use_dropout is not implemented (off by default)")
         self.act = get_activation_layer(activation)
         self.activation = _Marker(self.act)
         self.conv1 = ConvBlock(input_dim, output_dim, 3, 1, 1, padding_type=padding_type)
         self.conv2 = ConvBlock(output_dim, output_dim, 3, 1, 1, padding_type=padding_type)
         self.norm = AdaptiveInstanceNorm(output_dim, style_dim)
-        self.dropout = nn.Identity()
+        self.dropout = Dropout(0.5) if dropout else nn.Identity()
 
     def forward(self, x, z):
         y, sums = self.conv1(x, want_stats=True)
         h = self.norm(y, z, act=self.act, sums=sums)
         y, sums = self.conv2(h, want_stats=True)
+        if isinstance(self.dropout, Dropout) and self.training:
+            return ops.add(self.dropout(self.norm(y, z, sums=sums)), x)     # (the add cannot ride on the norm pass)
         return self.norm(y, z, res=x, sums=sums)
 
 
@@ -205,15 +208,13 @@ class DecResnetBlock(nn.Module):
 
     def __init__(self, n_channel, add_channel, norm_layer="instance", padding_type="reflect", stride=1, dropout=False):
         super().__init__()
-        if dropout:
-            raise NotImplementedError("--use_dropout is not implemented (off by default)")
         self.conv1 = ConvBlock(n_channel, n_channel, 3, stride=stride, padding=1, padding_type=padding_type)
         self.conv2 = ConvBlock(n_channel, n_channel, 3, stride=stride, padding=1, padding_type=padding_type)
         self.norm = _Marker("instance_norm", n_channel)
         nca = n_channel + add_channel
         self.block1 = nn.Sequential(nn.Conv2d(nca, nca, 1), _Marker("relu"), nn.Conv2d(nca, n_channel, 1), _Marker("relu"))
         self.block2 = nn.Sequential(nn.Conv2d(nca, nca, 1), _Marker("relu"), nn.Conv2d(nca, n_channel, 1), _Marker("relu"))
-        self.dropout = nn.Identity()
+        self.dropout = Dropout(0.5) if dropout else nn.Identity()
 
     @staticmethod
     def _mix(block, t):
@@ -226,4 +227,4 @@ class DecResnetBlock(nn.Module):
         out = self._mix(self.block1, torch.cat([out, ze], dim=1))
         out = ops.instance_norm_act(self.conv2(out))
         out = self._mix(self.block2, torch.cat([out, ze], dim=1))
-        return ops.add(out, x)
+        return ops.add(self.dropout(out), x)

@@ -29,6 +29,10 @@ class DeviceRandom:
     def z(self, shape, device):
         return torch.randn(shape, device=device)
 
+    def dropout_mask(self, shape, device, keep=0.5):
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return ops.bernoulli_mask(shape, keep, seed, 0, device)
+
 
 class ReplaySource:
     """Replays recorded draws in the reference's order."""
@@ -49,6 +53,9 @@ class ReplaySource:
 
     eps = z = _next
 
+    def dropout_mask(self, shape, device, keep=0.5):
+        return ops.canon(self._next(shape, device))
+
 
 _SOURCE = [DeviceRandom()]
 
@@ -66,3 +73,17 @@ class GaussianNoiseLayer(nn.Module):
         if not self.training:
             return x
         return random_source().add_noise(x)
+
+
+
+class Dropout(nn.Module):
+    """nn.Dropout(0.5) of the decoders' residual blocks (--use_dropout): identity in eval mode."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        return ops.dropout(x, random_source().dropout_mask(x.shape, x.device, 1.0 - self.p), self.p)

@@ -83,8 +83,16 @@ class TranslationModel(Model):
         out = self.model.style_encoder(img, c)
         return out if self.reparam else (out, None, None)
 
-    def _translate(self, contents, styles, classes):
+    def _translate(self, contents, styles, classes, per_call=None):
+        """Several translations in one decoder call.  ``per_call``: how many of the parts the reference feeds to ONE
+        decoder call -- with --use_dropout the calls are kept apart so the masks are drawn in the reference's order."""
         B = self.args.batch_size
+        if per_call and getattr(self.args, "use_dropout", False) and self.model.decoder.training:
+            outs = []
+            for i in range(0, len(contents), per_call):
+                sl = slice(i, i + per_call)
+                outs += list(self._translate(contents[sl], styles[sl], classes[sl]))
+            return tuple(outs)
         fake = self.model.decoder(ops.cat_batch(contents), torch.cat(styles, dim=0), torch.cat(classes, dim=0))
         return torch.split(fake, B, dim=0)
 
@@ -157,7 +165,7 @@ class TranslationModel(Model):
             # all four translations in ONE decoder call (per-sample AdaIN / LayerNorm: identical outputs, half
             # the launches, 4B images per GEMM)
             img_ba, img_br, img_ab, img_ar = self._translate((z_cb, z_cb, z_ca, z_ca), (z_sa, z_sr, z_sb, z_sr),
-                                                             (cls_a, cls_a, cls_b, cls_b))
+                                                             (cls_a, cls_a, cls_b, cls_b), per_call=2)
             img_fake = ops.cat_batch((img_ba, img_ab))
             img_random = ops.cat_batch((img_br, img_ar))
         # the gradient exchange of discriminator1 (side stream) overlaps discriminator2's forward + backward
@@ -258,7 +266,7 @@ class TranslationModel(Model):
         z_s, mu, logvar = self._encode_style(img, c_org)
         z_sa, z_sb = torch.split(z_s, B, dim=0)
         img_ba, img_aa, img_ab, img_bb = self._translate((z_cb, z_ca, z_ca, z_cb), (z_sa, z_sa, z_sb, z_sb),
-                                                         (cls_a, cls_a, cls_b, cls_b))    # one 4B-image decoder call
+                                                         (cls_a, cls_a, cls_b, cls_b), per_call=2)    # one 4B-image decoder call
         img_fake = ops.cat_batch((img_ba, img_ab))
         img_self = ops.cat_batch((img_aa, img_bb))
         # cross-cycle: re-encode the translations (note the swapped split order, adain_model.py:264-265)
@@ -295,7 +303,7 @@ class TranslationModel(Model):
         cls_a, cls_b = torch.split(c_org, B, dim=0)
         z_ca, z_cb = torch.split(self.model.content_encoder(img), B, dim=0)
         z_sr = self.get_z_random(B, a.latent_dim)
-        img_br, img_ar = self._translate((z_cb, z_ca), (z_sr, z_sr), (cls_a, cls_b))        # one 2B-image decoder call
+        img_br, img_ar = self._translate((z_cb, z_ca), (z_sr, z_sr), (cls_a, cls_b), per_call=1)        # one 2B-image decoder call
         img_random = ops.cat_batch((img_br, img_ar))
         # with --ms_dis the reference scores the random translations with discriminator1 (352-353)
         # ... and with --use_ragan the fake logits come from discriminator1, the real ones from discriminator2 (360-362)

@@ -82,11 +82,22 @@ def record_rng(log):
         t = o_normal(self, *a, **k)
         log.append(t.detach().clone().numpy())
         return t
-    torch.randn, torch.Tensor.normal_ = randn, normal_
+    import torch.nn.functional as F_
+    o_dropout = F_.dropout
+
+    def dropout(x, p=0.5, training=True, inplace=False):
+        # nn.Dropout.forward calls F.dropout; the mask of the fused torch op cannot be observed, so the recording run
+        # draws it explicitly with the same law (keep ~ Bernoulli(1 - p), scaled by 1 / (1 - p)) and logs it
+        if not training:
+            return x
+        m = torch.bernoulli(torch.full_like(x, 1.0 - p))
+        log.append(m.detach().clone().numpy())
+        return x * m / (1.0 - p)
+    torch.randn, torch.Tensor.normal_, F_.dropout = randn, normal_, dropout
     try:
         yield
     finally:
-        torch.randn, torch.Tensor.normal_ = o_randn, o_normal
+        torch.randn, torch.Tensor.normal_, F_.dropout = o_randn, o_normal, o_dropout
 
 
 def make_batch(B, D, H, W, seed):
@@ -273,6 +284,12 @@ def main():
         # updates the content discriminator (d_iter gating); 224x224 because Dc needs a >= 53x53 content map
         step_case("adain_step_dc", "AdaINModel", steps=2, seed=9, num_domains=2, batch_size=1, dim=4, crop_size=224,
                   use_dis_content=True)
+    if want("adain_step_dropout"):
+        step_case("adain_step_dropout", "AdaINModel", steps=1, seed=11, num_domains=2, batch_size=1, dim=4,
+                  use_dropout=True)
+    if want("base_step_concat_dropout"):
+        step_case("base_step_concat_dropout", "BaseModel", steps=1, seed=12, num_domains=2, batch_size=1, dim=4,
+                  concat=True, reparam=True, use_dropout=True)
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)

@@ -28,6 +28,9 @@ class TorchRng:
     def z(self, shape):          # adain_model.py:84  torch.randn(bs, latent_dim)
         return torch.randn(shape)
 
+    def mask(self, shape):       # nn.Dropout(0.5): keep-mask ~ Bernoulli(0.5)
+        return torch.bernoulli(torch.full(tuple(shape), 0.5))
+
 
 class ReplayRng:
     """Replays the list of tensors recorded from a reference run (tests/golden)."""
@@ -42,7 +45,7 @@ class ReplayRng:
         assert tuple(x.shape) == tuple(shape), (self.i, tuple(x.shape), tuple(shape))
         return x
 
-    noise = eps = z = _next
+    noise = eps = z = mask = _next
 
 
 class RecordingRng(TorchRng):
@@ -62,13 +65,16 @@ class RecordingRng(TorchRng):
     def z(self, shape):
         return self._rec(super().z(shape))
 
+    def mask(self, shape):
+        return self._rec(super().mask(shape))
+
 
 def default_args(**kw):
     """Namespace with the reference's flag defaults (arguments.py:18-51,85-118)."""
     a = dict(model="AdaINModel", input_dim=3, dim=64, num_domains=2, latent_dim=8, batch_size=1, crop_size=256,
              ms_dis=False, num_scales=3, use_dis_content=False, concat=False, reparam=False,
              lr=1e-4, wd=1e-4, beta1=0.5, beta2=0.999, n_iter_decay=600000, d_iter=3,
-             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla", use_ragan=False)
+             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla", use_ragan=False, use_dropout=False)
     a.update(kw)
     return SimpleNamespace(**a)
 
@@ -126,9 +132,13 @@ class OracleModel:
 
     def Dec(self, x, z, c):
         P = self.P["decoder"]
+        drop = nets._identity
+        if getattr(self.args, "use_dropout", False):                     # training mode: nn.Dropout(0.5) is live
+            rng = self._rng
+            drop = lambda t: t * rng.mask(t.shape).to(t.dtype) / 0.5     # noqa: E731
         if self.kind == "adain":
-            return nets.adain_decoder(P, x, z, c)
-        return nets.decoder_concat(P, x, z, c) if self.args.concat else nets.decoder_plain(P, x, z, c)
+            return nets.adain_decoder(P, x, z, c, drop)
+        return nets.decoder_concat(P, x, z, c, drop) if self.args.concat else nets.decoder_plain(P, x, z, c, drop)
 
     def D(self, which, x):
         P = self.P[which]
@@ -279,6 +289,7 @@ class OracleModel:
 
     def optimize_parameters(self, it, rng=None):            # adain_model.py:421-430
         rng = rng or TorchRng()
+        self._rng = rng                                         # (Dec draws its dropout masks from the same stream)
         if self.args.use_dis_content and it % self.args.d_iter != 0:
             self.update_content_discriminator(rng)
             return

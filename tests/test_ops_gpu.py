@@ -337,6 +337,39 @@ def test_spectral_norm_weight(shape, hip_device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout(dtype, hip_device):
+    """--use_dropout: x * mask / (1 - p) forward and gradient against torch with the same mask; the device-drawn mask
+    is 0/1 with keep fraction 1 - p, zero in the padding channels, reproducible per (seed, offset) and different
+    across seeds."""
+    ops = _ops(dtype)
+    x = _rnd(2, 12, 9, 7, seed=41)
+    m = (torch.rand(2, 12, 9, 7, generator=torch.Generator().manual_seed(42)) < 0.5).float()
+    xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+    yr = xr * m / 0.5
+    y = ops.dropout(xd, m.to(hip_device), 0.5)
+    g = _rnd(*yr.shape, seed=43)
+    yr.backward(g)
+    y.backward(g.to(hip_device))
+    _close(y, yr, dtype, what="dropout fwd", scale=2.0)
+    _close(xd.grad, xr.grad, dtype, what="dropout dx", scale=2.0)
+    a = ops.bernoulli_mask((4, 20, 64, 64), 0.5, 1234, 0, hip_device)
+    b = ops.bernoulli_mask((4, 20, 64, 64), 0.5, 1234, 0, hip_device)
+    c = ops.bernoulli_mask((4, 20, 64, 64), 0.5, 1235, 0, hip_device)
+    assert ops.is_canonical(a) and a.shape == (4, 20, 64, 64)
+    af = ops.to_nchw_f32(a)
+    assert set(af.unique().tolist()) == {0.0, 1.0}
+    assert abs(af.mean().item() - 0.5) < 5e-3                       # 327 680 draws: sigma = 9e-4
+    assert torch.equal(af, ops.to_nchw_f32(b)) and not torch.equal(af, ops.to_nchw_f32(c))
+    per_ch = af.mean(dim=(0, 2, 3))
+    assert (per_ch - 0.5).abs().max().item() < 2e-2                 # no channel is stuck
+    # padding channels (20 -> 24) stay zero
+    raw = a.permute(0, 2, 3, 1)                                      # logical NHWC view of the first 20 channels
+    assert raw.shape[-1] == 20
+    k25 = ops.to_nchw_f32(ops.bernoulli_mask((2, 8, 32, 32), 0.25, 7, 0, hip_device)).mean().item()
+    assert abs(k25 - 0.25) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layout_cat_noise(dtype, hip_device):
     ops = _ops(dtype)
     x = _rnd(3, 3, 8, 6, seed=1)
