@@ -290,6 +290,11 @@ def main():
     if want("base_step_concat_dropout"):
         step_case("base_step_concat_dropout", "BaseModel", steps=1, seed=12, num_domains=2, batch_size=1, dim=4,
                   concat=True, reparam=True, use_dropout=True)
+    if want("adain_step_norms"):
+        # non-default normalisation flags: LayerNorm in the content encoder, InstanceNorm in the decoder's upsampling
+        # blocks and in the discriminators
+        step_case("adain_step_norms", "AdaINModel", steps=1, seed=13, num_domains=2, batch_size=1, dim=4,
+                  enc_norm="layer", dec_norm="instance", dis_norm="instance")
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)

@@ -74,7 +74,8 @@ def default_args(**kw):
     a = dict(model="AdaINModel", input_dim=3, dim=64, num_domains=2, latent_dim=8, batch_size=1, crop_size=256,
              ms_dis=False, num_scales=3, use_dis_content=False, concat=False, reparam=False,
              lr=1e-4, wd=1e-4, beta1=0.5, beta2=0.999, n_iter_decay=600000, d_iter=3,
-             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla", use_ragan=False, use_dropout=False)
+             lambda_rec=10.0, lambda_cls=1.0, lambda_cls_G=5.0, gan_mode="vanilla", use_ragan=False, use_dropout=False, enc_norm="instance", dec_norm="layer",
+             dis_norm=None)
     a.update(kw)
     return SimpleNamespace(**a)
 
@@ -119,7 +120,7 @@ class OracleModel:
 
     # ---- network dispatch ----
     def Ec(self, x, rng):
-        h = nets.content_encoder(self.P["content_encoder"], x, None)
+        h = nets.content_encoder(self.P["content_encoder"], x, None, getattr(self.args, "enc_norm", "instance"))
         return h + rng.noise(h.shape) if rng is not None else h
 
     def Es(self, x, c, rng):
@@ -144,7 +145,7 @@ class OracleModel:
         P = self.P[which]
         if self.args.ms_dis:
             return nets.multi_scale_discriminator(P, x, self.args.num_scales)
-        return [nets.discriminator(P, x)]
+        return [nets.discriminator(P, x, getattr(self.args, "dis_norm", None))]
 
     # ---- step ----
     def update_lr(self):                                    # model.py:66-68

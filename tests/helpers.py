@@ -27,9 +27,10 @@ def checksum(t):
 def product_args(meta_args, tmpdir, precision="fp32", mode="train"):
     """Namespace for masterthesis_amd models from the args recorded in a fixture."""
     a = dict(meta_args)
+    a.setdefault("dis_norm", None)
     a.update(mode=mode, precision=precision, logdir=os.path.join(tmpdir, "logs"),
              checkpoint_dir=os.path.join(tmpdir, "ckpt"), display_dir=os.path.join(tmpdir, "img"),
-             gpu_ids=[0], resume=None, resume_opt=None, vgg_loss=None, dis_norm=None)
+             gpu_ids=[0], resume=None, resume_opt=None, vgg_loss=None)
     for d in (a["logdir"], a["checkpoint_dir"], a["display_dir"]):
         os.makedirs(d, exist_ok=True)
     return argparse.Namespace(**a)
