@@ -36,7 +36,7 @@ enum { MT_PAD_ZERO = 0, MT_PAD_REFLECT = 1 };
 enum { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU = 2, MT_ACT_TANH = 3 };
 /* which packed copy of a weight tensor */
 enum { MT_PACK_FWD = 0, MT_PACK_BWD_DATA = 1 };
-enum { MT_NORM_INSTANCE = 0, MT_NORM_ADAIN = 1, MT_NORM_LAYER = 2 };
+enum { MT_NORM_INSTANCE = 0, MT_NORM_ADAIN = 1, MT_NORM_LAYER = 2, MT_NORM_BATCH = 3 };
 
 /* Convolution problem: nn.Conv2d (blocks.py:33-35) preceded by nn.ReflectionPad2d
  * (functions.py:51) when pad_mode == MT_PAD_REFLECT, or nn.ConvTranspose2d (blocks.py:73)
@@ -134,6 +134,16 @@ int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const 
 int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
                       const float* shift, const float* c1, const float* c2, const float* c3,
                       void* dx, int N, int HW, int Cp, int act, float slope, mt_stream_t s);
+/* BatchNorm2d(affine, running statistics; functions.py:14-15) on the shared passes: bn_finalize pools the per-(n, c) sums
+ * of mt_nc_stats / mt_conv_fwd_stats over the batch (training: batch statistics + momentum update of the running
+ * buffers with the unbiased variance; eval: the running buffers) and fills the [N][Cp] coefficient arrays for
+ * mt_scale_shift_act; bn_bwd_finalize does the same for mt_norm_bwd_apply from mt_nc_stats_bwd's sums
+ * (dgamma, dbeta: [C]). */
+int mt_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, float eps, int training, float* scale, float* shift, float* mean, float* rstd, int N,
+                   int HW, int C, int Cp, mt_stream_t s);
+int mt_bn_bwd_finalize(const float* sums2, const float* mean, const float* rstd, const float* gamma, float* c1, float* c2,
+                       float* c3, float* dgamma, float* dbeta, int training, int N, int HW, int C, int Cp, mt_stream_t s);
 
 /* ---- elementwise / pooling / layout (K13, K14, K15, K19) ----------------------------- */
 int mt_act_fwd(int dtype, const void* x, void* y, size_t n, int act, float slope, mt_stream_t s);

@@ -14,7 +14,7 @@ MT_F32, MT_BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PACK_FWD, PACK_BWD_DATA = 0, 1
-NORM_INSTANCE, NORM_ADAIN, NORM_LAYER = 0, 1, 2
+NORM_INSTANCE, NORM_ADAIN, NORM_LAYER, NORM_BATCH = 0, 1, 2, 3
 GAN_LSGAN, GAN_HINGE_D, GAN_NEG_MEAN = 1, 2, 3
 
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_bn_finalize": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_bn_bwd_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mt_sn_ws_bytes": (_z, [_i, _i]),
     "mt_sn_power_iter": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _z, _p]),
     "mt_sn_scale_fwd": (_i, [_p, _p, _p, C.c_long, _p]),

@@ -376,3 +376,84 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
   MT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- BatchNorm2d (--enc_norm / --dec_norm / --dis_norm batch; functions.py:14-15: affine, running statistics) ---------------
+// Same four passes as the other norms: the per-(image, channel) sums are pooled over the batch here, the per-(n, c)
+// coefficient arrays are filled with the per-channel values so the elementwise kernels are shared.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float momentum, float eps, int training, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd, int N,
+                                   int HW, int C, int Cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  float m = 0.f, r = 0.f, sc = 0.f, sh = 0.f;
+  if (c < C) {
+    if (training) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int n = 0; n < N; n++) { s1 += sums[((long)n * Cp + c) * 2]; s2 += sums[((long)n * Cp + c) * 2 + 1]; }
+      const float cnt = (float)N * (float)HW;
+      m = s1 / cnt;
+      float var = s2 / cnt - m * m;
+      var = var > 0.f ? var : 0.f;
+      r = rsqrtf(var + eps);
+      // running statistics: momentum update with the UNBIASED variance, like torch
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (cnt / fmaxf(cnt - 1.f, 1.f));
+    } else {
+      m = rmean[c];
+      r = rsqrtf(rvar[c] + eps);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    sc = r * g; sh = b - m * sc;
+  }
+  for (int n = 0; n < N; n++) {
+    const long i = (long)n * Cp + c;
+    scale[i] = sc; shift[i] = sh; mean[i] = m; rstd[i] = r;
+  }
+}
+extern "C" int mt_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                              float* mean, float* rstd, int N, int HW, int C, int Cp, mt_stream_t s) {
+  MT_CHECK(running_mean != nullptr && running_var != nullptr, "bn_finalize: running statistics buffers are required");
+  MT_CHECK(!training || sums != nullptr, "bn_finalize: training mode needs the batch sums");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, N, HW, C, Cp);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+// dx = k1*g + k2 + k3*x (training: statistics depend on x; eval: running statistics are constants, k2 = k3 = 0)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums2, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int training, int N, int HW,
+                                       int C, int Cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+  if (c < C) {
+    float S1 = 0.f, S2 = 0.f;
+    for (int n = 0; n < N; n++) { S1 += sums2[((long)n * Cp + c) * 2]; S2 += sums2[((long)n * Cp + c) * 2 + 1]; }
+    const float m = mean[c], r = rstd[c];
+    const float gxh = r * (S2 - m * S1);
+    const float g = gamma ? gamma[c] : 1.f;
+    const float cnt = (float)N * (float)HW;
+    k1 = r * g;
+    if (training) {
+      k3 = -r * g * r * gxh / cnt;
+      k2 = -r * g * S1 / cnt - k3 * m;
+    }
+    if (dgamma) dgamma[c] = gxh;
+    if (dbeta) dbeta[c] = S1;
+  }
+  for (int n = 0; n < N; n++) {
+    const long i = (long)n * Cp + c;
+    c1[i] = k1; c2[i] = k2; c3[i] = k3;
+  }
+}
+extern "C" int mt_bn_bwd_finalize(const float* sums2, const float* mean, const float* rstd, const float* gamma, float* c1,
+                                  float* c2, float* c3, float* dgamma, float* dbeta, int training, int N, int HW, int C,
+                                  int Cp, mt_stream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums2, mean, rstd, gamma, c1, c2, c3, dgamma, dbeta, training, N, HW, C, Cp);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -560,14 +560,17 @@ def linear(x, weight, bias=None):
 class _Norm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gb, gamma, beta, res, sums, cfg):
-        mode, act, slope, eps = cfg
+        mode, act, slope, eps = cfg[:4]
+        bn = cfg[4] if len(cfg) > 4 else None           # BatchNorm: (running_mean, running_var, momentum, training)
         lib = L.load()
         x = canon(x)
         N, Cc, H, W = x.shape
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
-        if sums is None:
+        if bn is not None and not bn[3]:
+            sums = None                                  # eval mode: running statistics, no pass over x
+        elif sums is None:
             sums = _zero_stats((N, Cp, 2), dev)
             L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
         elif tuple(sums.shape) != (N, Cp, 2):
@@ -578,9 +581,15 @@ class _Norm(torch.autograd.Function):
         bt = None if beta is None else _f32c(beta.detach())
         if gbc is not None and tuple(gbc.shape) != (N, 2 * Cc):
             raise RuntimeError(f"adain: expected style projection of shape {(N, 2 * Cc)}, got {tuple(gbc.shape)}")
-        L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
-                                     _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, _stream()),
-                "mt_norm_finalize")
+        if mode == L.NORM_BATCH:
+            rm, rv, momentum, training = bn
+            L.check(lib.mt_bn_finalize(_ptr(sums), _ptr(gm), _ptr(bt), _ptr(rm), _ptr(rv), float(momentum), eps,
+                                       int(training), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc,
+                                       Cp, _stream()), "mt_bn_finalize")
+        else:
+            L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
+                                         _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, _stream()),
+                    "mt_norm_finalize")
         r = None if res is None else canon(res)
         y = new_act(N, Cc, H, W, x.dtype, dev)
         L.check(lib.mt_scale_shift_act(mt, _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(r), _ptr(y), N, HW, Cp, act,
@@ -593,7 +602,7 @@ class _Norm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
-        mode, act, slope, eps = ctx.cfg
+        mode, act, slope, eps = ctx.cfg[:4]
         x, coef, gbc, gm = ctx.saved_tensors
         dy = canon(dy)
         N, Cc, H, W = x.shape
@@ -606,12 +615,17 @@ class _Norm(torch.autograd.Function):
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
         dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
         dgamma = dbeta = None
-        if mode == L.NORM_LAYER and gm is not None:
+        if mode in (L.NORM_LAYER, L.NORM_BATCH) and gm is not None:
             dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
-        L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
-                                         _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
-                                         _ptr(dbeta), N, HW, Cc, Cp, _stream()), "mt_norm_bwd_finalize")
+        if mode == L.NORM_BATCH:
+            L.check(lib.mt_bn_bwd_finalize(_ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gm), _ptr(cc[0]), _ptr(cc[1]),
+                                           _ptr(cc[2]), _ptr(dgamma), _ptr(dbeta), int(ctx.cfg[4][3]), N, HW, Cc, Cp,
+                                           _stream()), "mt_bn_bwd_finalize")
+        else:
+            L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
+                                             _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
+                                             _ptr(dbeta), N, HW, Cc, Cp, _stream()), "mt_norm_bwd_finalize")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cc, H, W, x.dtype, dev)
@@ -634,6 +648,15 @@ def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
 def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
     """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
     return _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps)))
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, act=None, slope=0.01,
+                   eps=1e-5, sums=None):
+    """act(nn.BatchNorm2d(affine, running statistics)(x)): batch statistics + in-place momentum update of the running
+    buffers in training mode, the running buffers in eval mode (reference functions.py:14-15)."""
+    return _Norm.apply(x, None, gamma, beta, None, sums,
+                       (L.NORM_BATCH, _act_code(act), float(slope), float(eps),
+                        (running_mean, running_var, float(momentum), bool(training))))
 
 
 def layer_norm_act(x, gamma, beta, act=None, slope=0.01, eps=1e-5):

@@ -32,7 +32,17 @@ def _make_norm(name, dim):
         return LayerNorm(dim)
     if name == "instance":
         return _Marker("instance_norm", dim)
+    if name == "batch":
+        return nn.BatchNorm2d(dim)      # parameter / running-statistics holder (affine, momentum 0.1, eps 1e-5)
     raise NotImplementedError(f"norm '{name}' cannot be used inside a block")
+
+
+def _batch_norm(bn, y, sums, act, training):
+    """nn.BatchNorm2d semantics on the holder ``bn`` through the HIP kernels (running buffers updated in place)."""
+    if training:
+        bn.num_batches_tracked += 1
+    return ops.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training=training,
+                              momentum=bn.momentum, act=act, eps=bn.eps, sums=sums)
 
 
 class ConvBlock(nn.Module):
@@ -75,6 +85,15 @@ class ConvBlock(nn.Module):
             y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
                                  pad_mode=self.pad_mode, stats=True, bias_grad=False)
             return ops.instance_norm_act(y, act=self.act, res=res, sums=sums)
+        if self.norm == "batch":
+            if self.training:
+                y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
+                                     stats=True)
+            else:
+                y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
+                                     pad_mode=self.pad_mode), None
+            y = _batch_norm(self.block[self._ni], y, sums, self.act, self.training)
+            return y if res is None else ops.add(y, res)
         fused_act = self.act if self.norm is None else None
         y = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
                        act=fused_act)
@@ -129,6 +148,8 @@ class UpsampleBlock(nn.Module):
             return ops.instance_norm_act(y, act=self.act)
         if self.norm == "layer":
             return self.block[self._ni](y, act=self.act)
+        if self.norm == "batch":
+            return _batch_norm(self.block[self._ni], y, None, self.act, self.training)
         return y
 
 

@@ -24,8 +24,6 @@ def get_norm_layer(norm_layer="instance"):
         raise ValueError(f"parameter type of norm_layer should be 'str', but got {norm_layer}.")
     if norm_layer not in NORMS:
         raise NotImplementedError(f"norm type '{norm_layer}' is not supported at the moment")
-    if norm_layer == "batch":
-        raise NotImplementedError("norm type 'batch' has no HIP kernel in this build (non-default in the reference)")
     return norm_layer
 
 

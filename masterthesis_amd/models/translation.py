@@ -85,9 +85,11 @@ class TranslationModel(Model):
 
     def _translate(self, contents, styles, classes, per_call=None):
         """Several translations in one decoder call.  ``per_call``: how many of the parts the reference feeds to ONE
-        decoder call -- with --use_dropout the calls are kept apart so the masks are drawn in the reference's order."""
+        decoder call -- with --use_dropout the calls are kept apart so the masks are drawn in the reference's order, with
+        --dec_norm batch because the batch statistics are those of one call."""
         B = self.args.batch_size
-        if per_call and getattr(self.args, "use_dropout", False) and self.model.decoder.training:
+        apart = getattr(self.args, "use_dropout", False) or getattr(self.args, "dec_norm", None) == "batch"
+        if per_call and apart and self.model.decoder.training:
             outs = []
             for i in range(0, len(contents), per_call):
                 sl = slice(i, i + per_call)
@@ -204,7 +206,7 @@ class TranslationModel(Model):
         loss_d_adv, loss_d_cls = 0, 0
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:209; ms_dis goes via gan_loss)
         ragan = getattr(self.args, "use_ragan", False) and not self.args.ms_dis      # (adain_model.py:206-208)
-        if getattr(self.args, "dis_sn", False):
+        if getattr(self.args, "dis_sn", False) or getattr(self.args, "dis_norm", None) == "batch":
             # spectral norm runs one power iteration per forward call, so the weights of the two calls differ:
             # fake first, then real, as the reference does (adain_model.py:184-185, 203-205)
             outs_f = self._dis_outputs(netD, fake.detach())

@@ -295,6 +295,10 @@ def main():
         # blocks and in the discriminators
         step_case("adain_step_norms", "AdaINModel", steps=1, seed=13, num_domains=2, batch_size=1, dim=4,
                   enc_norm="layer", dec_norm="instance", dis_norm="instance")
+    if want("adain_step_bn"):
+        # BatchNorm2d everywhere a norm flag reaches (running statistics land in the post-step checksums); two steps
+        step_case("adain_step_bn", "AdaINModel", steps=2, seed=14, num_domains=2, batch_size=2, dim=4,
+                  enc_norm="batch", dec_norm="batch", dis_norm="batch")
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)

@@ -95,7 +95,7 @@ def hinge_dis(pr, pf):
 
 
 def _is_buffer(key):
-    return key.endswith(".weight_u") or key.endswith(".weight_v")
+    return key.endswith((".weight_u", ".weight_v", ".running_mean", ".running_var", ".num_batches_tracked"))
 
 
 class OracleModel:

@@ -337,6 +337,49 @@ def test_spectral_norm_weight(shape, hip_device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 16, 12, 12), (3, 20, 5, 7), (2, 64, 33, 31)])
+def test_batch_norm(shape, dtype, hip_device):
+    """nn.BatchNorm2d (--*_norm batch): training mode (batch statistics, running buffers updated in place with the
+    unbiased variance), its gradients (input, weight, bias), then eval mode on the updated running statistics."""
+    ops = _ops(dtype)
+    N, C, H, W = shape
+    ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref.weight.copy_(_rnd(C, seed=51) * 0.5 + 1.0)
+        ref.bias.copy_(_rnd(C, seed=52) * 0.1)
+    gw, gb = ref.weight.detach().clone().to(hip_device).requires_grad_(), ref.bias.detach().clone().to(hip_device).requires_grad_()
+    rm, rv = ref.running_mean.clone().to(hip_device), ref.running_var.clone().to(hip_device)
+    for call in range(2):
+        x = _rnd(*shape, seed=53 + call) * 1.5 + 0.3
+        xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+        ref.train()
+        ref.zero_grad()
+        gw.grad = gb.grad = None
+        yr = F.leaky_relu(ref(xr), 0.01)
+        y = ops.batch_norm_act(xd, gw, gb, rm, rv, training=True, momentum=0.1, act="lrelu")
+        g = _rnd(*shape, seed=60 + call)
+        yr.backward(g)
+        y.backward(g.to(hip_device))
+        _close(y, yr, dtype, what="bn fwd")
+        _close(xd.grad, xr.grad, dtype, what="bn dx", scale=2.0)
+        _close(gw.grad, ref.weight.grad, dtype, what="bn dgamma", scale=float(N * H * W) ** 0.5)
+        _close(gb.grad, ref.bias.grad, dtype, what="bn dbeta", scale=float(N * H * W) ** 0.5)
+        assert (rm.cpu() - ref.running_mean).abs().max().item() < (1e-5 if dtype == torch.float32 else 5e-3)
+        assert (rv.cpu() - ref.running_var).abs().max().item() < (1e-5 if dtype == torch.float32 else 1e-2)
+    ref.eval()
+    x = _rnd(*shape, seed=70)
+    xr, xd = x.clone().requires_grad_(), x.to(hip_device).requires_grad_()
+    rm0 = rm.clone()
+    yr = ref(xr)
+    y = ops.batch_norm_act(xd, gw, gb, rm, rv, training=False)
+    yr.backward(g)
+    y.backward(g.to(hip_device))
+    assert torch.equal(rm0, rm), "eval mode must not touch the running statistics"
+    _close(y, yr, dtype, what="bn eval fwd")
+    _close(xd.grad, xr.grad, dtype, what="bn eval dx", scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dropout(dtype, hip_device):
     """--use_dropout: x * mask / (1 - p) forward and gradient against torch with the same mask; the device-drawn mask
     is 0/1 with keep fraction 1 - p, zero in the padding channels, reproducible per (seed, offset) and different

@@ -60,7 +60,7 @@ def _fp64_truth(z, meta, it_count):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan",
                                   "adain_step_hinge", "adain_step_ragan", "adain_step_nearest", "adain_step_sn", "adain_step_dc", "base_step_concat", "adain_step_dropout",
-                                  "base_step_concat_dropout", "adain_step_norms"])
+                                  "base_step_concat_dropout", "adain_step_norms", "adain_step_bn"])
 def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     z, meta, M, misc = _build(name, tmp_path, precision)
     torch.set_num_threads(8)
