@@ -63,6 +63,37 @@ def test_train_cli_optional_flags(flags, tmp_path, hip_device):
     assert "model_4.ckpt" in os.listdir(ck)
 
 
+def test_sample_cli_end_to_end(tmp_path, hip_device, monkeypatch):
+    """sample.py's command line on an image folder (reference sample.py:79-224): a checkpoint written by train.py, two
+    images resized to 540x960, translated into two target domains with random styles and with reference images."""
+    import numpy as np
+    from PIL import Image
+    from masterthesis_amd import sample, train
+    common = ["--model", "AdaINModel", "--num_domains", "4", "--dim", "8", "--num_workers", "0", "--batch_size", "1"]
+    train.main(common + ["--dataset", "SyntheticDataset", "--exp_dir", str(tmp_path), "--name", "run", "--crop_size", "64",
+                         "--synthetic_len", "2", "--print_freq", "100", "--save_freq", "1", "--display_freq", "100",
+                         "--n_iters", "1", "--max_iter", "1"])
+    ckpt = os.path.join(str(tmp_path), "run", "checkpoints", "model_0.ckpt")
+    src = tmp_path / "frames"
+    os.makedirs(src)
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, (90, 160, 3), dtype=np.uint8)).save(src / f"f{i}.png")
+    out = tmp_path / "out"
+    monkeypatch.chdir(tmp_path)           # (the grid modes write ./grid.png like the reference)
+    base = common + ["--dataroot", str(src), "--resume", ckpt, "--result_dir", str(out), "--precision", "bf16"]
+    sample.Sampler().run(base + ["--targets", "fog", "sun"])
+    for trg in ("1", "3"):
+        files = sorted(os.listdir(out / "images" / trg))
+        assert len(files) == 2, files
+        img = Image.open(out / "images" / trg / files[0])
+        assert img.size == (960, 540)
+    sample.Sampler().run(base + ["--targets", "rain", "--reference", str(src / "f1.png"), "--eval"])
+    assert len(os.listdir(out / "images" / "2")) == 2
+    sample.Sampler().run(base + ["--gen_grid", "--targets", "cloud", "fog"])
+    assert os.path.isfile(tmp_path / "grid.png")
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_inference_surface(precision, tmp_path, hip_device):
     import argparse
