@@ -35,8 +35,10 @@ def test_train_cli_checkpoint_resume(tmp_path, hip_device):
 @pytest.mark.parametrize("flags", [["--dis_sn"], ["--gan_mode", "hinge", "--up_type", "nearest"],
                                    ["--gan_mode", "lsgan", "--use_ragan"], ["--ms_dis", "--crop_size", "256"],
                                    ["--use_dis_content", "--crop_size", "224", "--d_iter", "2"], ["--use_dropout"],
-                                   ["--enc_norm", "batch", "--dec_norm", "batch", "--dis_norm", "batch", "--batch_size", "2"]],
-                         ids=["dis_sn", "hinge_nearest", "lsgan_ragan", "ms_dis", "dis_content", "dropout", "batch_norm"])
+                                   ["--enc_norm", "batch", "--dec_norm", "batch", "--dis_norm", "batch", "--batch_size", "2"],
+                                   ["--model", "BaseModel", "--concat", "--reparam"], ["--model", "BaseModel"]],
+                         ids=["dis_sn", "hinge_nearest", "lsgan_ragan", "ms_dis", "dis_content", "dropout", "batch_norm",
+                              "base_concat_reparam", "base_plain"])
 def test_train_cli_optional_flags(flags, tmp_path, hip_device):
     """Every optional flag of SURVEY 8f-4 through the command line: three iterations in bf16, a checkpoint, a resume;
     for --dis_sn the checkpoint carries the reference's spectral-norm keys and the power-iteration vectors move."""
