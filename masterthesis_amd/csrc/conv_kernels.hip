@@ -100,10 +100,15 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 
   unsigned wo32[WLD];
   unsigned wokm = 0;
+  // 16-byte epilogue stores (as in the ping-pong kernel): within each 32-row fragment pair LDS row (a&1)*16 + r holds
+  // channel (r>>2)*8 + (a&1)*4 + (r&3), so fragments (2s, 2s+1) of lane group fg end up with the 8 CONSECUTIVE channels
+  // s*32 + fg*8 .. +7 of a pixel
+  constexpr bool PERM = (WT % 32 == 0);
 #pragma unroll
   for (int i = 0; i < WLD; i++) {
     const int rl = r0 + RPP * i;
-    const int row = wt * WT + rl;
+    const int rch = PERM ? ((rl & ~31) | ((((rl & 15) >> 2) << 3) | (((rl >> 4) & 1) << 2) | (rl & 3))) : rl;
+    const int row = wt * WT + rch;
     const bool ok = (rl < WT) && (row < p.CoRows);
     wokm |= (ok ? 1u : 0u) << i;
     wo32[i] = ((unsigned)(ok ? row : 0) * (unsigned)ph.wrow + (unsigned)c) * 16u;
@@ -262,13 +267,27 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   }
   if (p.raw) {
     // split-K partial: the fp32 accumulators go to this phase's slab; bias / activation are applied by the finish
+    if constexpr (PERM) {
 #pragma unroll
-    for (int a = 0; a < FC; a++) {
-      const int co = wt * WT + wcI * WC + a * 16 + fg * 4;
-      if (co >= p.Co) continue;
+      for (int sp = 0; sp < FC / 2; sp++) {
+        const int co = wt * WT + wcI * WC + sp * 32 + fg * 8;
+        if (co >= p.Co) continue;
 #pragma unroll
-      for (int b = 0; b < FP; b++)
-        if (yp[b] != nullptr) *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = acc[a][b];
+        for (int b = 0; b < FP; b++)
+          if (yp[b] != nullptr) {
+            *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = acc[2 * sp][b];
+            *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4 + 16) = acc[2 * sp + 1][b];
+          }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < FC; a++) {
+        const int co = wt * WT + wcI * WC + a * 16 + fg * 4;
+        if (co >= p.Co) continue;
+#pragma unroll
+        for (int b = 0; b < FP; b++)
+          if (yp[b] != nullptr) *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = acc[a][b];
+      }
     }
     return;
   }
@@ -280,6 +299,49 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const bool do_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(&sW[0][0]);     // [NWP][WT][2]
   if (do_stats) __syncthreads();                        // every wave is done reading the last weight tile
+  if constexpr (PERM) {
+#pragma unroll
+    for (int sp = 0; sp < FC / 2; sp++) {
+      const int col = wcI * WC + sp * 32 + fg * 8;
+      const int co = wt * WT + col;
+      if (co >= p.Co) continue;
+      float bv[8], s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        bv[e] = (p.bias != nullptr && (co + e) < p.nbias) ? p.bias[co + e] : 0.f;
+        s1[e] = s2[e] = 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        if (yp[b] == nullptr) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope);
+          s1[e] += v[e];
+          s2[e] += v[e] * v[e];
+        }
+        if constexpr (BF16) {
+          u32x4 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+          *reinterpret_cast<u32x4*>(yp[b] + (size_t)co * 2) = o;
+        } else {
+          f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = o0;
+          *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4 + 16) = o1;
+        }
+      }
+      if (do_stats) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+          if (fr == 0) {
+            red[((wpI * WT) + col + e) * 2] = t1;
+            red[((wpI * WT) + col + e) * 2 + 1] = t2;
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int a = 0; a < FC; a++) {
     const int col = wcI * WC + a * 16 + fg * 4;         // channel within the block tile
@@ -317,6 +379,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
         }
       }
     }
+  }
   }
   if (do_stats) {
     __syncthreads();
