@@ -43,81 +43,72 @@ def model_args(o, tmp):
 
 
 def cpu_baseline(o, args):
-    """The CPU oracle (port of the reference step) on a bounded sample: ONE full G+D step at batch 1 and a
-    reduced resolution, scaled by the pixel ratio (the step's work is linear in H*W)."""
+    """The CPU oracle (a port of the reference step to plain torch CPU ops, pinned against the reference by
+    tests/golden) on this host's cores, as SURVEY.md section 8(d) specifies: batch_size 1 (2 images) at the bench
+    resolution, fp32, 1 warm-up step + ``--cpu_steps`` timed steps (default 2); the thread count is stated.  A time guard
+    keeps the default run bounded: if the warm-up step alone took more than ``--cpu_budget_s`` / 3 the timed steps are
+    cut to one."""
     from oracle import step as ostep
     from masterthesis_amd.dataset import SyntheticDataset
     from masterthesis_amd.models.core import networks as N
-    res = o.cpu_res
+    res = o.cpu_res or o.crop_size
+    ms = bool(o.ms_dis and res >= 256)
     torch.manual_seed(0)
     nets = {"content_encoder": N.ContentEncoder(3, dim=64),
             "style_encoder": N.ReparameterizedStyleEncoder(3, output_dim=8, dim=64, num_domains=o.num_domains,
                                                            norm_layer=None, activation="lrelu"),
             "decoder": N.AdaINDecoder(3, dim=256, num_domains=o.num_domains, latent_dim=8)}
     for k in ("discriminator1", "discriminator2"):
-        nets[k] = (N.MultiScaleDiscriminator(3, num_domains=o.num_domains) if o.ms_dis and res >= 256 else
+        nets[k] = (N.MultiScaleDiscriminator(3, num_domains=o.num_domains) if ms else
                    N.Discriminator(3, dim=64, num_domains=o.num_domains, image_size=res))
     from masterthesis_amd.models.core.functions import init_weights
     params = {}
     for k, n in nets.items():
         init_weights(n, "normal", 0.02)
         params[k] = n.state_dict()
-    oa = ostep.default_args(model="AdaINModel", dim=64, num_domains=o.num_domains, batch_size=1, crop_size=res,
-                            ms_dis=bool(o.ms_dis and res >= 256))
+    oa = ostep.default_args(model="AdaINModel", dim=64, num_domains=o.num_domains, batch_size=1, crop_size=res, ms_dis=ms)
     O = ostep.OracleModel(params, oa)
-    a2 = argparse.Namespace(crop_size=res, num_domains=o.num_domains, synthetic_len=1)
-    item = SyntheticDataset(a2, length=1, seed=99)[0]
-    batch = {k: v.unsqueeze(0) for k, v in item.items()}
+    a2 = argparse.Namespace(crop_size=res, num_domains=o.num_domains, synthetic_len=4)
+    ds = SyntheticDataset(a2, length=4, seed=99)
     cores = torch.get_num_threads()
-    t0 = time.time()
-    O.update_lr()
-    O.set_inputs(batch)
-    O.optimize_parameters(0)
-    dt = time.time() - t0
+
+    def step(it):
+        batch = {k: v.unsqueeze(0) for k, v in ds[it % 4].items()}
+        t0 = time.time()
+        O.update_lr()
+        O.set_inputs(batch)
+        O.optimize_parameters(it)
+        return time.time() - t0
+    warm = step(0)
+    n_timed = o.cpu_steps if warm * (1 + o.cpu_steps) <= o.cpu_budget_s else 1
+    times = [step(1 + i) for i in range(n_timed)]
+    dt = sum(times) / len(times)
     scale = (res * res) / float(o.crop_size * o.crop_size)
-    return {"value": 2.0 / dt * scale, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 full G+D step of the CPU oracle, batch_size 1 (2 images), {res}x{res}, fp32, "
-                      f"{dt:.1f} s wall; scaled by the pixel ratio ({res}^2/{o.crop_size}^2) to {o.crop_size}x{o.crop_size}"}
+    note = "" if res == o.crop_size else f"; scaled by the pixel ratio ({res}^2/{o.crop_size}^2) to {o.crop_size}x{o.crop_size}"
+    return {"value": round(2.0 / dt * scale, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+            "s_per_step": round(dt, 2), "warmup_step_s": round(warm, 2), "timed_steps": n_timed,
+            "sample": f"CPU oracle (port of the reference step, torch CPU ops), full G+D step, batch_size 1 (2 images), "
+                      f"{res}x{res}, fp32, {'multi' if ms else 'single'}-scale D, {cores} threads: 1 warm-up step "
+                      f"({warm:.1f} s) + {n_timed} timed step(s), mean {dt:.1f} s{note}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch_size", type=int, default=8, help="pairs per GPU per step (BASELINE config 2: 8)")
-    ap.add_argument("--crop_size", type=int, default=256)
-    ap.add_argument("--num_domains", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--ms_dis", action="store_true", help="multi-scale discriminators (default: single-scale, "
-                    "the reference's default)")
-    ap.add_argument("--cpu_res", type=int, default=128, help="resolution of the bounded CPU-baseline sample")
-    ap.add_argument("--no_cpu_baseline", action="store_true")
-    o = ap.parse_args()
-
-    from masterthesis_amd.distributed import init_from_env
-    rank, world, local = init_from_env()
-    if world != o.gpus:
-        raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {o.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+def timed_run(o, rank, world, dev, steps, warmup, time_k1):
+    """Build the model for ``o`` and time ``steps`` full G+D steps (after ``warmup`` untimed ones) between
+    barrier + synchronize; -> (seconds [max over ranks], K1 launch timings, final losses)."""
     import torch.distributed as dist
     from masterthesis_amd import hip_ops as ops
     from masterthesis_amd import models
     from masterthesis_amd.dataset import SyntheticDataset
-
     tmp = tempfile.mkdtemp()
     args = model_args(o, tmp)
-    torch.manual_seed(0)
+    torch.manual_seed(0)                    # identical initial weights; rank r then draws from seed 0 + r (Model.initialize)
     M = models.AdaINModel(args)
     M.initialize()
     ds = SyntheticDataset(args, length=8, seed=1234 + rank)
     nb = 2
     batches = []
     for b in range(nb):     # synthetic batches, already resident in HBM before the timed region
-        items = [ds[b * o.batch_size + i] for i in range(o.batch_size)]
+        items = [ds[(b * o.batch_size + i) % 8] for i in range(o.batch_size)]
         batches.append({k: torch.stack([it[k] for it in items]).to(dev) for k in items[0]})
 
     def one_step(it):
@@ -130,32 +121,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(o.warmup):
+    for it in range(warmup):
         one_step(it)
-    N_img = 2 * o.batch_size
-    k1_m = N_img * (o.crop_size // 4) ** 2
 
     def is_k1(d):
         return (not d.transposed and d.kh == 3 and d.stride == 1 and d.Ci == 256 and d.Co == 256
                 and d.H == o.crop_size // 4)
     barrier()
-    ops.kernel_timer_start(is_k1)
+    if time_k1:
+        ops.kernel_timer_start(is_k1)
     t0 = time.time()
-    for it in range(o.warmup, o.warmup + o.steps):
+    for it in range(warmup, warmup + steps):
         one_step(it)
     barrier()
     dt = time.time() - t0
-    k1_ms = ops.kernel_timer_stop()
+    k1_ms = ops.kernel_timer_stop() if time_k1 else []
     losses = M.sync_losses()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    del M, batches
+    torch.cuda.empty_cache()
+    return dt, k1_ms, losses
+
+
+def step_numbers(o, dt, steps, world):
+    ms_per_step = dt / steps * 1e3
+    f_step = F_STEP_TFLOP[bool(o.ms_dis)] * o.batch_size * (o.crop_size ** 2 / 65536.0)
+    peak = PEAK_BF16_TFLOPS if o.precision == "bf16" else PEAK_F32_TFLOPS
+    return {"images_per_sec": round(2 * o.batch_size * world * steps / dt, 3), "ms_per_step": round(ms_per_step, 3),
+            "step_tflop_algorithmic": round(f_step, 2),
+            "step_tflops_achieved_per_gpu": round(f_step / (ms_per_step * 1e-3), 1),
+            "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4)}
+
+
+def workload_name(o):
+    return (f"AdaINModel full G+D step, {o.num_domains} domains, {o.crop_size}x{o.crop_size}, batch_size {o.batch_size} "
+            f"pairs/GPU ({2 * o.batch_size} images/GPU/step), {'multi-scale' if o.ms_dis else 'single-scale'} "
+            f"discriminators, {o.precision}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=8, help="pairs per GPU per step (BASELINE config 2: 8)")
+    ap.add_argument("--crop_size", type=int, default=256)
+    ap.add_argument("--num_domains", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--ms_dis", action="store_true", help="multi-scale discriminators for the headline run (default: "
+                    "single-scale, the reference's default; the --ms_dis step is always reported under 'extra')")
+    ap.add_argument("--cpu_res", type=int, default=0, help="resolution of the CPU-baseline steps (0 = the bench resolution)")
+    ap.add_argument("--cpu_steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
+    ap.add_argument("--cpu_budget_s", type=float, default=240.0)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_extra", action="store_true", help="skip the additional configurations reported under 'extra'")
+    o = ap.parse_args()
+
+    from masterthesis_amd.distributed import init_from_env
+    rank, world, local = init_from_env()
+    if world != o.gpus:
+        raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {o.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    dt, k1_ms, losses = timed_run(o, rank, world, dev, o.steps, o.warmup, time_k1=True)
+    # other configurations of BASELINE.json / SURVEY 8(d), measured in this same process right after the headline run
+    # (single GPU only: the multi-GPU runs are the driver's scaling curve of the headline configuration)
+    extra = {}
+    if world == 1 and not o.no_extra:
+        import copy
+        variants = []
+        if not o.ms_dis:
+            variants.append(("ms_dis", dict(ms_dis=True)))
+        else:
+            variants.append(("single_scale", dict(ms_dis=False)))
+        variants.append(("configs2_d4_b16_ms_dis", dict(num_domains=4, batch_size=16, ms_dis=True)))
+        variants.append(("configs2_d4_b16_single_scale", dict(num_domains=4, batch_size=16, ms_dis=False)))
+        variants.append(("fp32" if o.precision == "bf16" else "bf16",
+                         dict(precision="fp32" if o.precision == "bf16" else "bf16")))
+        variants.append(("batch_size_1", dict(batch_size=1)))       # the reference's scripts/train.sh batch size
+        for name, kw in variants:
+            o2 = copy.copy(o)
+            for k, v in kw.items():
+                setattr(o2, k, v)
+            k = max(3, min(o.steps, 10))
+            dt2, _, _ = timed_run(o2, rank, world, dev, k, 3, time_k1=False)
+            extra[name] = dict(workload=workload_name(o2), steps=k, warmup=3, **step_numbers(o2, dt2, k, world))
     if rank != 0:
         return
-    ms_per_step = dt / o.steps * 1e3
-    value = N_img * world * o.steps / dt
-    f_step = F_STEP_TFLOP[bool(o.ms_dis)] * o.batch_size * (o.crop_size ** 2 / 65536.0)
+    N_img = 2 * o.batch_size
+    k1_m = N_img * (o.crop_size // 4) ** 2
+    nums = step_numbers(o, dt, o.steps, world)
     peak = PEAK_BF16_TFLOPS if o.precision == "bf16" else PEAK_F32_TFLOPS
     # dominant kernel: forward implicit GEMM, M = 2B*(H/4)^2 pixels, N = 256 couts, K = 9*256
     # (phase 4 runs the decoder on half batches: count each launch with its own pixel count)
@@ -165,38 +226,42 @@ def main():
     tot_flop = sum(2.0 * n * (o.crop_size // 4) ** 2 * 256 * 2304 for _, n in k1_ms)
     tot_ms = sum(t for t, _ in k1_ms)
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if k1_ms else 0.0
-    # HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE x2 correction +
-    # WRITE_SIZE, MI355X_MICROARCH.md) collected with tools/bench_k1.py on this exact shape; see profiles/
-    traffic, mfma_busy = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "round1_k1_fwd_pmc.json")
-    if os.path.exists(pmc_path) and o.precision == "bf16" and o.batch_size == 8 and o.crop_size == 256:
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        traffic, mfma_busy = pmc.get("traffic_bytes_per_launch"), pmc.get("mfma_busy_fraction")
+    # HBM-side traffic of the dominant kernel per launch is NOT measured in this run: it is copied from the committed
+    # rocprofv3 PMC passes of this exact shape (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md; collected
+    # with tools/pmc_k1.sh) and labelled as such
+    traffic, mfma_busy, pmc_src = None, None, None
+    for cand in ("round2_k1_fwd_pmc.json", "round1_k1_fwd_pmc.json"):
+        pmc_path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(pmc_path) and o.precision == "bf16" and o.batch_size == 8 and o.crop_size == 256:
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic, mfma_busy = pmc.get("traffic_bytes_per_launch"), pmc.get("mfma_busy_fraction")
+            pmc_src = "profiles/" + cand
+            break
     out = {
-        "metric": "train images/sec (G+D step), AdaINModel 256x256", "value": round(value, 3), "unit": "images/sec",
-        "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": round(ms_per_step, 3),
+        "metric": "train images/sec (G+D step), AdaINModel 256x256", "value": nums["images_per_sec"], "unit": "images/sec",
+        "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": nums["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if o.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"AdaINModel full G+D step, {o.num_domains} domains, {o.crop_size}x{o.crop_size}, "
-                               f"batch_size {o.batch_size} pairs/GPU ({N_img} images/GPU/step), "
-                               f"{'multi-scale' if o.ms_dis else 'single-scale'} discriminators, {o.precision}",
+        "config": {"workload": workload_name(o),
                    "global_batch_pairs": o.batch_size * world, "parallelism": f"dp{world}",
-                   "step_tflop_algorithmic": round(f_step, 2),
-                   "step_tflops_achieved_per_gpu": round(f_step / (ms_per_step * 1e-3), 1),
-                   "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4)},
+                   "step_tflop_algorithmic": nums["step_tflop_algorithmic"],
+                   "step_tflops_achieved_per_gpu": nums["step_tflops_achieved_per_gpu"],
+                   "step_frac_of_mfma_peak": nums["step_frac_of_mfma_peak"]},
         "roofline": {"bound": "mfma", "kernel": ("igemm_pipe_kernel<bf16,256,256,512,4>" if o.precision == "bf16" else
                                                  "igemm_pipe_kernel<f32,256,256,512,4>") + " fwd 3x3 s1 256->256 @64x64 "
                                                 "(+ fused InstanceNorm-statistics epilogue)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": pmc_src,
                      "mfma_busy_fraction_pmc": mfma_busy,
                      "launches_timed": len(k1_ms), "avg_launch_ms_full_batch": round(k1_avg_ms, 4),
                      "flop_per_launch_full_batch": k1_flop},
         "final_losses": {k: round(float(v), 5) for k, v in losses.items()},
     }
+    if extra:
+        out["extra"] = extra
     if world == 1 and not o.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(o, args)
+        out["cpu_baseline"] = cpu_baseline(o, None)
     print(json.dumps(out), flush=True)
 
 

@@ -53,6 +53,11 @@ class Arguments:
         # additions of this implementation
         p.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
                        help="activation storage / MFMA input type (accumulation and statistics are always fp32)")
+        p.add_argument("--seed", type=int, default=None,
+                       help="(new, optional) base random seed; rank r of a multi-GPU run draws from seed + r")
+        p.add_argument("--ckpt_module_prefix", action="store_true",
+                       help="(new, optional) save model_*.ckpt with 'module.'-prefixed keys, as the reference's "
+                            "DataParallel-wrapped GPU runs write and strictly expect them")
         p.add_argument("--synthetic_len", type=int, default=64, help="items per epoch of SyntheticDataset")
 
     def _finish(self, args):
@@ -107,6 +112,8 @@ class TrainArguments(Arguments):
         p.add_argument("--ms_dis", action="store_true")
         p.add_argument("--dis_sn", action="store_true")
         p.add_argument("--num_scales", type=int, default=3)
+        p.add_argument("--ms_dim", type=int, default=64,
+                       help="(new, optional) width of the multi-scale discriminators; the reference hard-wires 64")
         p.add_argument("--use_ragan", action="store_true")
         p.add_argument("--lambda_perceptual", type=float, default=1.0)
         p.add_argument("--vgg_type", type=str, default="vgg19")

@@ -18,8 +18,8 @@ class SyntheticDataset(Dataset):
     def __init__(self, args, return_paths=False, length=None, seed=None):
         self.args = args
         self.size = int(length if length is not None else getattr(args, "synthetic_len", 64))
-        rank = int(os.environ.get("RANK", "0"))
-        self.seed = int(seed if seed is not None else 1234 + rank)
+        # the same dataset on every rank: the train loop's DistributedSampler hands each rank its own indices
+        self.seed = int(seed if seed is not None else 1234)
         self.targets = list(range(args.num_domains))
 
     def __len__(self):

@@ -29,6 +29,39 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def rank_and_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def seed_rank_streams(base=None, group=None):
+    """Give every rank its OWN random streams: the content noise, the reparameterisation eps,
+    z_random and the dropout masks are per-sample draws, so replicas that all start from torch's default seed would
+    train on duplicated noise.  Called after the weights were broadcast, so initialisation stays identical.
+    ``base`` defaults to the seed the process already has (``torch.manual_seed(s)`` before building the model keeps
+    meaning "reproducible run"); rank r reseeds the CPU and the device generator with ``base + r`` (rank 0 is left
+    exactly as it was, so a single-process run is unchanged).  Returns the seed in use."""
+    import random
+    rank, world = rank_and_world(group)
+    base = int(torch.initial_seed() if base is None else base)
+    if world <= 1:
+        return base
+    # everyone agrees on rank 0's base seed (ranks may have been started with different ones)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([base], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0, group=group)
+    base = int(t.item())
+    if rank == 0:
+        return base
+    seed = (base + rank) % (2 ** 63)
+    torch.manual_seed(seed)                 # CPU generator (Philox seeds of the noise / dropout kernels) + all devices
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    random.seed(seed)
+    return seed
+
+
 class GradReducer:
     """All-reduce (mean) of flat gradient buffers, asynchronously on a side stream when on GPU.
 

@@ -988,6 +988,11 @@ def neg_mean(x):
     return _GanConst.apply(x, L.GAN_NEG_MEAN, 1.0)
 
 
+def signed_mean(x, negative):
+    """-x.mean() (negative) or x.mean(): GANLoss 'wgangp' (loss.py:53-57)"""
+    return _GanConst.apply(x, L.GAN_NEG_MEAN, 1.0 if negative else 0.0)
+
+
 class _SubMean(torch.autograd.Function):
     """y = x - mean(other) on logit maps (the relativistic-average GAN terms, adain_model.py:206-208): composed of
     the existing kernels -- mean via mt_gan_const_fwd(NEG_MEAN), the shift via mt_scale_shift_act, and in the

@@ -6,15 +6,16 @@ from ... import hip_ops as ops
 
 
 class GANLoss(nn.Module):
-    """'vanilla' (BCE with logits) and 'lsgan' (MSE) against constant ones / zeros.  With 'hinge' the reference
+    """'vanilla' (BCE with logits) and 'lsgan' (MSE) against constant ones / zeros; 'wgangp' = -mean(x) for a real
+    target, +mean(x) for a fake one (loss.py:53-57; the reference has no gradient penalty term).  With 'hinge' the reference
     never calls this module (its ``self.loss`` is None, loss.py:46-47): the hinge terms are written out in the model
     (adain_model.py:209-210, 293-295) -- ``hinge_dis`` / ``hinge_gen`` below are those expressions."""
 
     def __init__(self, loss="vanilla"):
         super().__init__()
-        if loss not in ("vanilla", "lsgan", "hinge"):
-            raise NotImplementedError(f"gan_mode '{loss}' is not implemented in this build ('bce' needs sigmoid outputs, "
-                                      "'wgangp' has no gradient penalty in the reference either)")
+        if loss not in ("vanilla", "lsgan", "hinge", "wgangp"):
+            raise NotImplementedError(f"gan_mode '{loss}' is not implemented in this build ('bce' is nn.BCELoss on raw "
+                                      "logits in the reference, which torch rejects outside [0, 1])")
         self.loss_type = loss
 
     def forward(self, inp, trg_is_real, is_dis=None):
@@ -22,6 +23,8 @@ class GANLoss(nn.Module):
             return ops.bce_logits_const(inp, bool(trg_is_real))
         if self.loss_type == "lsgan":
             return ops.mse_const(inp, bool(trg_is_real))
+        if self.loss_type == "wgangp":
+            return ops.signed_mean(inp, negative=bool(trg_is_real))
         raise TypeError("'NoneType' object is not callable")      # what the reference raises for 'hinge' here
 
     @staticmethod

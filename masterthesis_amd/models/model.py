@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip_ops as ops
-from ..distributed import GradReducer, broadcast_parameters
+from ..distributed import GradReducer, broadcast_parameters, seed_rank_streams
 from ..utils import AttributeDict, save_image_grid
 from .core.functions import get_scheduler, init_net
 
@@ -76,8 +76,11 @@ class Model(ABC, nn.Module):
             self.load(self.args.resume, self.args.resume_opt)
         else:
             self.load(self.args.resume)
-        # replicas start from rank 0's weights
-        broadcast_parameters([p.data for net in self.model for p in self.model[net].parameters()])
+        # replicas start from rank 0's weights AND buffers (spectral-norm u / v, BatchNorm running statistics) ...
+        broadcast_parameters([p.data for net in self.model for p in self.model[net].parameters()] +
+                             [b.data for net in self.model for b in self.model[net].buffers()])
+        # ... but draw their own noise / eps / z_random / dropout masks
+        self.rng_seed = seed_rank_streams()
 
     def init_scheduler(self):
         for opt in self.optimizer:
@@ -96,7 +99,10 @@ class Model(ABC, nn.Module):
                 self.scheduler[net].step()
 
     def save(self, it):
-        model_state = {net: self.model[net].state_dict() for net in self.model}
+        # --ckpt_module_prefix: write the keys the reference's default GPU run expects -- its init_net wraps every
+        # network in nn.DataParallel (functions.py:98-101), so its strict load_state_dict wants 'module.'-prefixed keys
+        pre = "module." if getattr(self.args, "ckpt_module_prefix", False) else ""
+        model_state = {net: {pre + k: v for k, v in self.model[net].state_dict().items()} for net in self.model}
         torch.save(model_state, os.path.join(self.args.checkpoint_dir, f"model_{it}.ckpt"))
         opt_state = {opt: self.optimizer[opt].state_dict() for opt in self.optimizer}
         torch.save(opt_state, os.path.join(self.args.checkpoint_dir, f"opt_{it}.ckpt"))

@@ -41,7 +41,9 @@ class TranslationModel(Model):
             return
         if args.ms_dis:
             def make_d():
-                return networks.MultiScaleDiscriminator(args.input_dim, norm_layer=args.dis_norm, sn=args.dis_sn,
+                # the reference never passes ``dim`` (adain_model.py:33-42): width 64 unless --ms_dim says otherwise
+                return networks.MultiScaleDiscriminator(args.input_dim, dim=getattr(args, "ms_dim", None) or 64,
+                                                        norm_layer=args.dis_norm, sn=args.dis_sn,
                                                         num_domains=args.num_domains, num_scales=args.num_scales)
         else:
             def make_d():

@@ -16,6 +16,9 @@ from . import hip_ops as ops
 class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=weight_decay)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdam keeps ONE flat buffer with one set of hyper-parameters: pass a single parameter "
+                             "group (the reference builds one Adam per network, adain_model.py:57-71)")
         self._flat = None
         self._step_count_mt = 0
 
@@ -87,12 +90,20 @@ class FusedAdam(torch.optim.Adam):
         ops.bump_epoch(self.params())
         ops.repack_params(self.params())    # all cached weight images of this network, one launch
 
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise ValueError("FusedAdam supports a single parameter group")
+        super().add_param_group(param_group)
+
     def state_dict(self):
-        for p in self.params():
-            if p in self.state and "step" in self.state[p]:
-                self.state[p]["step"] = torch.tensor(float(self._step_count_mt))
+        if self._flat is not None:      # (before the first flatten the per-parameter 'step' entries are authoritative)
+            for p in self.params():
+                if p in self.state and "step" in self.state[p]:
+                    self.state[p]["step"] = torch.tensor(float(self._step_count_mt))
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        steps = [int(torch.as_tensor(s["step"]).item()) for s in self.state.values() if "step" in s]
+        self._step_count_mt = max(steps) if steps else 0
         self._flat = None   # re-flatten (copies the loaded moments) at the next use

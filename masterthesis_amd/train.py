@@ -9,7 +9,7 @@ and image dump (all three fire at iteration 0, like the reference); stops after
 import torch
 
 from .arguments import TrainArguments
-from .distributed import init_from_env
+from .distributed import init_from_env, rank_and_world
 from .utils import TimerBlock
 
 
@@ -21,7 +21,12 @@ class Trainer:
             block.log("Create dataloader")
             # the reference hard-codes shuffle=False (train.py:19); drop_last avoids the short last batch
             # that breaks torch.split(..., batch_size) there
-            dataloader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=False,
+            # one process per GPU: every rank iterates its own strided share of the indices (the reference's single
+            # process feeds all GPUs from one loader through nn.DataParallel's scatter)
+            _, world = rank_and_world()
+            sampler = (torch.utils.data.distributed.DistributedSampler(dataset, shuffle=False, drop_last=True)
+                       if world > 1 else None)
+            dataloader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=False, sampler=sampler,
                                                      num_workers=args.num_workers, drop_last=True,
                                                      pin_memory=torch.cuda.is_available())
         return dataloader
@@ -65,6 +70,8 @@ class Trainer:
 
     def run(self, args):
         rank, world, local = init_from_env()
+        if getattr(args, "seed", None) is not None:
+            torch.manual_seed(args.seed)        # (the reference never seeds; ranks get seed + rank after initialize())
         dataloader = self.load_dataset(args)
         model = self.create_model(args)
         self.train(args, model, dataloader, rank)

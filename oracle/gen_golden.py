@@ -126,12 +126,36 @@ def _flat_sums(prefix, sd, out):
         out[f"{prefix}/{k}"] = checksum(v.detach())
 
 
-def step_case(name, model_name, steps=2, seed=0, full_grads=(0,), **kw):
+@contextlib.contextmanager
+def ms_width(dim):
+    """The reference's AdaINModel builds MultiScaleDiscriminator without passing ``dim`` (adain_model.py:33-42), so its
+    width is the class default 64 -> 2048 channels (44.7 M parameters each: too large for a committed fixture and for a
+    float64 CPU run).  The recording run changes ONLY that constructor default for the duration of the model construction, so the
+    step logic being pinned (182-199, 278-285, 352-359) is the reference's own, on a narrow discriminator; the product
+    reaches the same width through its optional ``--ms_dim`` flag."""
+    from models.core import networks as N
+    if dim is None:
+        yield
+        return
+    init = N.MultiScaleDiscriminator.__init__
+    orig = init.__defaults__
+    assert init.__code__.co_varnames[2] == "dim" and orig[0] == 64
+    init.__defaults__ = (dim,) + orig[1:]
+    try:
+        yield
+    finally:
+        init.__defaults__ = orig
+
+
+def step_case(name, model_name, steps=2, seed=0, full_grads=(0,), ms_dim=None, **kw):
     """One or two full optimize_parameters() calls of the imported reference."""
     import models  # the reference package
     args = ref_args(**kw)
+    if ms_dim is not None:
+        args.ms_dim = ms_dim            # (read by nobody in the reference; recorded in meta for the product's --ms_dim)
     torch.manual_seed(seed)
-    M = getattr(models, model_name)(args)
+    with ms_width(ms_dim):
+        M = getattr(models, model_name)(args)
     M.initialize()
     # nn.Linear layers keep torch's default init (functions.py:72-94 only touches Conv*)
     out = {}
@@ -302,6 +326,16 @@ def main():
     if want("adain_step_ragan"):
         step_case("adain_step_ragan", "AdaINModel", steps=1, seed=6, num_domains=2, batch_size=1, dim=4,
                   use_ragan=True)
+    if want("adain_step_ms"):
+        # --ms_dis (the north-star discriminator): 3-scale loss sums (adain_model.py:182-199), the multi-scale generator
+        # term (278-285) and the discriminator1-in-phase-4 quirk (352-353), 4 domains, two iterations at 256x256 (the
+        # smallest size the 6-layer k4 s2 stack accepts at 3 scales)
+        step_case("adain_step_ms", "AdaINModel", steps=2, seed=15, num_domains=4, batch_size=1, dim=4, crop_size=256,
+                  ms_dis=True, ms_dim=4)
+    if want("adain_step_wgangp"):
+        # --gan_mode wgangp: GANLoss returns -mean / +mean (loss.py:53-57); the reference has no gradient penalty
+        step_case("adain_step_wgangp", "AdaINModel", steps=1, seed=16, num_domains=2, batch_size=1, dim=4,
+                  gan_mode="wgangp")
     return 0
 
 

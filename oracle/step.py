@@ -86,6 +86,8 @@ def gan_loss(mode, x, real):
         return F.binary_cross_entropy_with_logits(x, torch.ones_like(x) if real else torch.zeros_like(x))
     if mode == "lsgan":
         return F.mse_loss(x, torch.ones_like(x) if real else torch.zeros_like(x))
+    if mode == "wgangp":                                     # loss.py:53-57 (no gradient penalty in the reference)
+        return -x.mean() if real else x.mean()
     raise NotImplementedError(mode)
 
 

@@ -148,3 +148,49 @@ def test_sharded_gradients_equal_global_batch_gloo():
             got = torch.from_numpy(out[rank][i])
             rel = ((got - ref[n]).norm() / ref[n].norm()).item()
             assert rel < 1e-9, f"rank {rank} {n}: sharded+all-reduced gradient differs from global batch by {rel}"
+
+
+def _worker_product_model(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import argparse
+    from helpers import load_gold, product_args
+    from masterthesis_amd import dataset, models
+    from masterthesis_amd.distributed import init_from_env
+    from masterthesis_amd.train import Trainer
+    init_from_env(backend="gloo")
+    _, meta = load_gold("adain_step_sn")                # spectral norm: the u / v BUFFERS must be broadcast too
+    args = product_args(meta["args"], os.path.join(tmp, str(rank)))
+    args.dataset, args.num_workers, args.synthetic_len = dataset.SyntheticDataset, 0, 8
+    torch.manual_seed(1000 * (rank + 1))                # deliberately different initial weights per rank
+    M = models.AdaINModel(args)
+    M.initialize()                                      # -> rank 0's weights everywhere, then per-rank random streams
+    state = torch.cat([t.detach().flatten().double() for net in M.model for t in M.model[net].state_dict().values()])
+    draws = (torch.randn(4).tolist(), int(torch.randint(0, 2 ** 62, (1,)).item()))
+    loader = Trainer().load_dataset(args)
+    first = next(iter(loader))
+    q.put((rank, state.sum().item(), state.abs().sum().item(), M.rng_seed, draws, first["x1"].double().sum().item(),
+           len(loader)))
+    dist.destroy_process_group()
+
+
+def test_product_model_two_ranks_same_weights_different_streams(tmp_path):
+    """What the reference gets from one process feeding nn.DataParallel (functions.py:98-101), restated for one process
+    per GPU: replicas start from identical weights and buffers, but every rank reads its own share of the dataset and
+    draws its own noise / eps / z_random (ranks used to be seeded identically and read the same files)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_product_model, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, a0, seed0, d0, x0, n0), (_, s1, a1, seed1, d1, x1, n1) = out
+    assert (s0, a0) == (s1, a1), "replicas do not start from the same weights / buffers"
+    assert seed1 == seed0 + 1 and d0 != d1, "ranks draw from the same random stream"
+    assert x0 != x1, "ranks read the same samples"
+    assert n0 == n1 == 8 // 2 // 1                      # 8 items, 2 ranks, batch_size 1

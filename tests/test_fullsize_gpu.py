@@ -103,9 +103,21 @@ def test_decoder_batch_split_invariance_fullsize(dtype, otol, gtol, hip_device):
     assert num / den < gtol, f"decoder parameter gradients differ: rel L2 {num / den:.2e}"
 
 
-@pytest.mark.parametrize("ms_dis", [False, True], ids=["single_scale", "multi_scale"])
-def test_full_size_step_runs_and_is_finite(ms_dis, tmp_path, hip_device):
-    """Two full-size steps (config 2) in bf16: every loss finite, parameters move, no NaN in any network."""
+FULL_SIZE_CONFIGS = {
+    # BASELINE.json configs[1]: 2 domains, 256x256, batch 8
+    "configs1_single_scale": dict(num_domains=2, batch_size=8, crop_size=256, ms_dis=False),
+    "configs1_multi_scale": dict(num_domains=2, batch_size=8, crop_size=256, ms_dis=True),
+    # configs[2] (and the per-GPU share of configs[3]): 4 domains, 256x256, batch 16, multi-scale discriminators
+    "configs2_d4_b16_multi_scale": dict(num_domains=4, batch_size=16, crop_size=256, ms_dis=True),
+    # the per-GPU workload shape of configs[4]: 4 domains, 512x512 (batch 2 pairs)
+    "configs4_d4_512_multi_scale": dict(num_domains=4, batch_size=2, crop_size=512, ms_dis=True),
+}
+
+
+@pytest.mark.parametrize("cfg", list(FULL_SIZE_CONFIGS))
+def test_full_size_step_runs_and_is_finite(cfg, tmp_path, hip_device):
+    """Two full-size steps in bf16 at the sizes BASELINE.json names: every loss finite and in the range of a GAN at
+    initialisation, parameters of every network move, no NaN anywhere."""
     import argparse
     import sys
     import os
@@ -113,13 +125,13 @@ def test_full_size_step_runs_and_is_finite(ms_dis, tmp_path, hip_device):
     import bench
     from masterthesis_amd import models
     from masterthesis_amd.dataset import SyntheticDataset
-    o = argparse.Namespace(precision="bf16", num_domains=2, batch_size=8, crop_size=256, ms_dis=ms_dis)
+    o = argparse.Namespace(precision="bf16", **FULL_SIZE_CONFIGS[cfg])
     args = bench.model_args(o, str(tmp_path))
     torch.manual_seed(0)
     M = models.AdaINModel(args)
     M.initialize()
     ds = SyntheticDataset(args, length=8, seed=7)
-    items = [ds[i] for i in range(o.batch_size)]
+    items = [ds[i % 8] for i in range(o.batch_size)]
     batch = {k: torch.stack([it[k] for it in items]).to(hip_device) for k in items[0]}
     before = {n: torch.cat([p.detach().flatten()[:1000].float() for p in M.model[n].parameters()]).clone() for n in M.model}
     for it in range(2):
@@ -129,6 +141,11 @@ def test_full_size_step_runs_and_is_finite(ms_dis, tmp_path, hip_device):
     losses = M.sync_losses()
     for k, v in losses.items():
         assert v == v and abs(v) < 1e6, f"loss {k} = {v}"
+    # at initialisation (N(0, 0.02) weights) every logit is ~0: BCE terms sit at ln 2 per term
+    import math
+    n_scales = 3 if o.ms_dis else 1
+    assert abs(losses["d_adv"] - 2 * n_scales * math.log(2)) < 0.05 * n_scales, losses["d_adv"]
+    assert abs(losses["g_cls"] - 5 * n_scales * math.log(2)) < 0.2 * n_scales, losses["g_cls"]
     for n in M.model:
         after = torch.cat([p.detach().flatten()[:1000].float() for p in M.model[n].parameters()])
         assert torch.isfinite(after).all(), f"{n} has non-finite parameters"

@@ -156,3 +156,42 @@ def test_attribute_dict_and_loss_keys():
     d.a = 1
     d["b"] = 2
     assert d.a == 1 and d.b == 2 and d.missing is None and list(d) == ["a", "b"]
+
+
+def test_checkpoint_module_prefix_option_writes_dataparallel_keys(tmp_path):
+    """--ckpt_module_prefix: the other direction of the interchange -- the reference's default GPU run wraps
+    every net in nn.DataParallel (functions.py:98-101) and its strict load_state_dict expects 'module.' keys."""
+    from masterthesis_amd import models
+    z, meta = load_gold("adain_step_d2")
+    args = product_args(meta["args"], str(tmp_path))
+    args.ckpt_module_prefix = True
+    M = models.AdaINModel(args)
+    M.save(3)
+    ck = torch.load(os.path.join(args.checkpoint_dir, "model_3.ckpt"))
+    for net, sd in ck.items():
+        assert all(k.startswith("module.") for k in sd), net
+        wrapped = torch.nn.DataParallel(torch.nn.Sequential())       # a DataParallel-style key set: module.<key>
+        want = {"module." + k for k in sub(z, f"init/{net}")}
+        assert set(sd) == want, net
+        del wrapped
+    M2 = models.AdaINModel(args)
+    M2.load(os.path.join(args.checkpoint_dir, "model_3.ckpt"))      # and it still loads here
+
+
+def test_fused_adam_keeps_loaded_step_count(tmp_path):
+    """load_state_dict -> state_dict before any step must not reset Adam's step counter."""
+    from masterthesis_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 3))]
+    ref = torch.optim.Adam(ps, lr=1e-3)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    sd = ref.state_dict()
+    opt = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    opt.load_state_dict(sd)
+    out = opt.state_dict()
+    assert all(int(s["step"]) == 3 for s in out["state"].values())
+    assert opt._step_count_mt == 3
+    with pytest.raises(ValueError):
+        FusedAdam([{"params": [ps[0]]}, {"params": [ps[1]], "lr": 1.0}])

@@ -78,7 +78,7 @@ def _run_step_case(name):
 
 @pytest.mark.parametrize("name", ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan",
                                   "adain_step_hinge", "adain_step_ragan", "adain_step_nearest", "adain_step_sn", "adain_step_dc", "base_step_concat", "adain_step_dropout",
-                                  "base_step_concat_dropout", "adain_step_norms", "adain_step_bn"])
+                                  "base_step_concat_dropout", "adain_step_norms", "adain_step_bn", "adain_step_ms", "adain_step_wgangp"])
 def test_training_step_matches_reference(name):
     torch.set_num_threads(4)
     z, meta, M, batch = _run_step_case(name)
