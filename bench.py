@@ -102,8 +102,10 @@ def timed_run(o, rank, world, dev, steps, warmup, time_k1):
     tmp = tempfile.mkdtemp()
     args = model_args(o, tmp)
     torch.manual_seed(0)                    # identical initial weights; rank r then draws from seed 0 + r (Model.initialize)
-    M = models.AdaINModel(args)
-    M.initialize()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # ("initialize network with ..." lines: stdout carries the JSON line only)
+        M = models.AdaINModel(args)
+        M.initialize()
     ds = SyntheticDataset(args, length=8, seed=1234 + rank)
     nb = 2
     batches = []

@@ -83,9 +83,13 @@ size_t mt_conv_fwd_ws_bytes(const mt_conv_desc* d);
 int mt_conv_fwd_ex(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                    void* y, void* ws, size_t ws_bytes, mt_stream_t s);
 /* Forward with the normalisation statistics of the output fused into the GEMM epilogue:
- * stats [N][Cp][2] = {sum, sum of squares} over H*W per (image, channel) -- the mt_nc_stats() result, so
- * the InstanceNorm/AdaIN/LayerNorm that follows (blocks.py:38-42,158-164) skips its statistics pass.
- * d->act must be MT_ACT_NONE; the caller passes stats ZERO-FILLED (the epilogue accumulates into it). */
+ * stats [N][Cp][2] = {sum, sum of squares} over H*W per (image, channel) -- one "partial row" per image in the
+ * sense of mt_nc_stats (nparts = 1), so the InstanceNorm/AdaIN/LayerNorm that follows (blocks.py:38-42,158-164)
+ * skips its statistics pass.  Only for shapes with mt_conv_fwd_stats_fused(d) != 0 (plain convolution, no
+ * activation, Ho*Wo a multiple of 256); the caller passes stats ZERO-FILLED (the epilogue accumulates into it with
+ * fp32 atomics: the one statistics path whose summation order varies from run to run -- callers that need
+ * bit-reproducible runs use mt_conv_fwd + mt_nc_stats instead). */
+int mt_conv_fwd_stats_fused(const mt_conv_desc* d);
 int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                       void* y, float* stats, mt_stream_t s);
 size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d);
@@ -108,29 +112,33 @@ int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, fl
                   float* db, int n, int in, int out, int accumulate, mt_stream_t s);
 
 /* ---- normalisation family (K9, K10, K11): functions.py:17, norm.py:5-33 -------------- */
-/* sums[n][c] += {sum x, sum x^2} over H*W (fp32, [N][Cp][2]); the CALLER zeroes sums (fp32 atomics from
- * several blocks per image, same contract as the stats of mt_conv_fwd_stats). */
-int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);
+/* Statistics pass: part[n][k][c] = {sum x, sum x^2} over the k-th pixel block of image n (fp32,
+ * [N][nparts][Cp][2], nparts = mt_nc_stats_parts(dtype, N, HW, Cp) <= 64; every element is written, nothing to
+ * zero).  Fixed summation order inside a block and in the finalize kernels, which add the nparts rows of an
+ * image in index order: results are bit-reproducible. */
+int mt_nc_stats_parts(int dtype, int N, int HW, int Cp);
+int mt_nc_stats(int dtype, const void* x, float* part, int N, int HW, int Cp, mt_stream_t s);
 /* scale/shift [N][Cp] for y = act(scale*x + shift); mean/rstd saved for backward.
  * mode INSTANCE: gamma=beta=NULL.  ADAIN: gb = fc(s) [N][2*C] (weight = 1+gb[:, :C], bias =
  * gb[:, C:]).  LAYER: per-sample statistics over (C,H,W); gamma,beta [C] (norm.py:16-21). */
 int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* gamma,
                      const float* beta, float* scale, float* shift, float* mean, float* rstd,
-                     int N, int HW, int C, int Cp, float eps, mt_stream_t s);
+                     int N, int HW, int C, int Cp, float eps, int nparts, mt_stream_t s);
 /* y = act(scale[n][c]*x + shift[n][c]) (+ res).  res may be NULL. */
 int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
                        const void* res, void* y, int N, int HW, int Cp, int act, float slope,
                        mt_stream_t s);
-/* g = dy * act'(scale*x+shift); sums2[n][c] += {sum g, sum g*x}; the CALLER zeroes sums2. */
+/* g = dy * act'(scale*x+shift); part2[n][k][c] = {sum g, sum g*x} over pixel block k (layout and nparts as
+ * mt_nc_stats). */
 int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale,
-                    const float* shift, float* sums2, int N, int HW, int Cp, int act,
+                    const float* shift, float* part2, int N, int HW, int Cp, int act,
                     float slope, mt_stream_t s);
 /* coefficients for dx = c1*g + c2 + c3*x; plus parameter gradients:
  * ADAIN: dgb [N][2C]; LAYER: dgamma, dbeta [C]. */
 int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const float* rstd,
                          const float* gb, const float* gamma, float* c1, float* c2, float* c3,
                          float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,
-                         mt_stream_t s);
+                         int nparts, mt_stream_t s);
 int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
                       const float* shift, const float* c1, const float* c2, const float* c3,
                       void* dx, int N, int HW, int Cp, int act, float slope, mt_stream_t s);
@@ -141,9 +149,10 @@ int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* sca
  * (dgamma, dbeta: [C]). */
 int mt_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    float momentum, float eps, int training, float* scale, float* shift, float* mean, float* rstd, int N,
-                   int HW, int C, int Cp, mt_stream_t s);
+                   int HW, int C, int Cp, int nparts, mt_stream_t s);
 int mt_bn_bwd_finalize(const float* sums2, const float* mean, const float* rstd, const float* gamma, float* c1, float* c2,
-                       float* c3, float* dgamma, float* dbeta, int training, int N, int HW, int C, int Cp, mt_stream_t s);
+                       float* c3, float* dgamma, float* dbeta, int training, int N, int HW, int C, int Cp, int nparts,
+                       mt_stream_t s);
 
 /* ---- elementwise / pooling / layout (K13, K14, K15, K19) ----------------------------- */
 int mt_act_fwd(int dtype, const void* x, void* y, size_t n, int act, float slope, mt_stream_t s);

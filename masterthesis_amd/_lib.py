@@ -54,11 +54,13 @@ SIGNATURES = {
     "mt_conv_bwd_weight": (_i, [_dp, _p, _p, _p, _p, _p, _z, _i, _p]),
     "mt_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_conv_fwd_stats_fused": (_i, [_dp]),
+    "mt_nc_stats_parts": (_i, [_i, _i, _i, _i]),
     "mt_nc_stats": (_i, [_i, _p, _p, _i, _i, _i, _p]),
-    "mt_norm_finalize": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "mt_norm_finalize": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "mt_scale_shift_act": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mt_nc_stats_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
-    "mt_norm_bwd_finalize": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_norm_bwd_finalize": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mt_norm_bwd_apply": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mt_act_fwd": (_i, [_i, _p, _p, _z, _i, _f, _p]),
     "mt_act_bwd": (_i, [_i, _p, _p, _p, _z, _i, _f, _p]),
@@ -70,8 +72,8 @@ SIGNATURES = {
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_upsample2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
-    "mt_bn_finalize": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "mt_bn_bwd_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mt_bn_finalize": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mt_bn_bwd_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mt_sn_ws_bytes": (_z, [_i, _i]),
     "mt_sn_power_iter": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _z, _p]),
     "mt_sn_scale_fwd": (_i, [_p, _p, _p, C.c_long, _p]),

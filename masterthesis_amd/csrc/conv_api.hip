@@ -376,11 +376,19 @@ extern "C" int mt_conv_fwd(const mt_conv_desc* d, const void* x, const void* pac
   return mt_conv_fwd_ex(d, x, pack_fwd, bias, y, nullptr, 0, st);
 }
 
-extern "C" int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s);
+static bool stats_fusable(const mt_conv_desc* d) {
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  return !d->transposed && d->act == MT_ACT_NONE && ((Ho * Wo) % 256 == 0);   // a block's pixel tile stays inside one image
+}
+extern "C" int mt_conv_fwd_stats_fused(const mt_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return stats_fusable(d) ? 1 : 0;
+}
 
 // Forward + per-(image, channel) {sum, sum^2} of the output (the InstanceNorm / AdaIN / LayerNorm
-// statistics pass).  Fused into the GEMM epilogue when a wave's pixels cannot straddle two images;
-// otherwise the separate statistics kernel runs.  stats: fp32 [N][Cop][2], MUST BE ZERO on entry (the
+// statistics pass), fused into the GEMM epilogue; only for shapes where a wave's pixels cannot straddle two
+// images (mt_conv_fwd_stats_fused).  stats: fp32 [N][Cop][2], MUST BE ZERO on entry (the
 // epilogue accumulates with atomics).
 extern "C" int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const void* pack_fwd, const float* bias,
                                  void* y, float* stats, mt_stream_t st) {
@@ -391,11 +399,8 @@ extern "C" int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const voi
   int Ho, Wo;
   mt_conv_out_hw(d, &Ho, &Wo);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
-  const bool fuse = !d->transposed && ((Ho * Wo) % 256 == 0);   // a block's pixel tile stays inside one image
-  if (!fuse) {
-    if (mt_conv_fwd(d, x, pack_fwd, bias, y, st)) return 2;
-    return mt_nc_stats(d->dtype, y, stats, d->N, Ho * Wo, Cop, st);
-  }
+  MT_CHECK(stats_fusable(d), "conv_fwd_stats: this shape has no fused statistics epilogue (mt_conv_fwd_stats_fused() == 0): "
+                             "run mt_conv_fwd followed by mt_nc_stats");
   return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, stats);
 }
 

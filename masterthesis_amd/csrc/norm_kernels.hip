@@ -4,42 +4,70 @@
 // Reference: functions.py:17,32-34; norm.py:5-33; blocks.py:38-42,83-87,158-167.
 //
 // All three share the same four HBM passes:
-//   forward : mt_nc_stats (sum, sum^2 per (n,c))  ->  mt_norm_finalize (tiny)  ->
+//   forward : mt_nc_stats (partial sum, sum^2 per (n, pixel block, c))  ->  mt_norm_finalize (tiny)  ->
 //             mt_scale_shift_act  y = act(scale[n,c]*x + shift[n,c]) (+res)
-//   backward: mt_nc_stats_bwd (sum g, sum g*x)    ->  mt_norm_bwd_finalize (tiny) ->
+//   backward: mt_nc_stats_bwd (partial sum g, sum g*x)    ->  mt_norm_bwd_finalize (tiny) ->
 //             mt_norm_bwd_apply   dx = c1[n,c]*g + c2[n,c] + c3[n,c]*x,  g = dy*act'(.)
-// Statistics are fp32; per-thread partial sums, LDS tree over the pixel lanes of a block,
-// then one fp32 atomic per (block, channel).
+// Statistics are fp32 and REPRODUCIBLE: a block reduces its pixel range in a fixed order and writes one partial
+// row [Cp][2]; the finalize kernels add the rows of an image in index order.  No atomics, nothing to zero.
 #include "mt_common.h"
 
-// block = cchunks channel-chunks x npl pixel lanes.  grid = (pixel blocks, N)
+// Geometry shared by the statistics kernels: 256 threads = npl pixel lanes x cchunks 16-byte channel chunks,
+// nparts pixel blocks per image (<= 64), about eight blocks per CU for the big maps.
+static inline void stats_geometry(int N, int HW, int cchunks, int* ppb, int* nparts) {
+  const int npl = 256 / cchunks;
+  long want = 2048 / (N > 0 ? N : 1);
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  long p = (HW + want - 1) / want;
+  const long pmin = (long)npl * 4;            // at least four pixels per thread
+  if (p < pmin) p = pmin;
+  p = (p + npl - 1) / npl * npl;
+  *ppb = (int)p;
+  *nparts = cdiv(HW, p);
+}
+extern "C" int mt_nc_stats_parts(int dtype, int N, int HW, int Cp) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  if (cchunks < 1 || cchunks > 256 || HW <= 0) return 1;
+  int ppb, nparts;
+  stats_geometry(N, HW, cchunks, &ppb, &nparts);
+  return nparts;
+}
+
+// grid = (nparts, N).  Thread (pl, cq) walks pixels p0 + pl, p0 + pl + npl, ... with U independent 16-byte loads
+// (2U backward) in flight, then ONE pass through LDS combines the pixel lanes in a fixed order.
 template <bool BF16, bool BWD>
-__global__ __launch_bounds__(1024) void nc_stats_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
-                                                       const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, float* __restrict__ sums,
-                                                       int HW, int cchunks, int pix_per_block, int act,
-                                                       float slope) {
+__global__ __launch_bounds__(256) void nc_stats_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ part,
+                                                      int HW, int cchunks, int pix_per_block, int act,
+                                                      float slope) {
   constexpr int V = Elem<BF16>::V;
-  __shared__ float red[1024 * 2];
+  constexpr int NV = 2 * V;
+  constexpr int U = 4;
+  constexpr int STR = 257;                     // LDS row stride (floats): the output pass walks rows, keep them on distinct banks
+  __shared__ float red[NV * STR];
   const int n = blockIdx.y;
-  const int cq = threadIdx.x % cchunks;
-  const int pl = threadIdx.x / cchunks;
-  const int npl = blockDim.x / cchunks;
+  const int tid = threadIdx.x;
+  const int cq = tid % cchunks;
+  const int pl = tid / cchunks;
+  const int npl = 256 / cchunks;
   const int Cp = cchunks * V;
-  const long base = (long)n * HW * cchunks;
+  const long base = (long)n * HW * cchunks + cq;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
   float s1[V], s2[V], sc[V], sh[V];
 #pragma unroll
   for (int e = 0; e < V; e++) { s1[e] = 0.f; s2[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
-  if (BWD && pl < npl) {
-#pragma unroll
-    for (int e = 0; e < V; e++) {
-      sc[e] = scale[(long)n * Cp + cq * V + e];
-      sh[e] = shift[(long)n * Cp + cq * V + e];
-    }
-  }
   if (pl < npl) {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        sc[e] = scale[(long)n * Cp + cq * V + e];
+        sh[e] = shift[(long)n * Cp + cq * V + e];
+      }
+    }
     auto accum = [&](const u32x4& xv, const u32x4& gv) {
       float f[V];
       Elem<BF16>::unpack(xv, f);
@@ -57,67 +85,95 @@ __global__ __launch_bounds__(1024) void nc_stats_kernel(const u32x4* __restrict_
         for (int e = 0; e < V; e++) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
       }
     };
-    // two pixels per iteration: 2 (4 backward) independent 16-byte loads in flight per thread
     int px = p0 + pl;
-    for (; px + npl < p1; px += 2 * npl) {
-      const long i0 = base + (long)px * cchunks + cq, i1 = i0 + (long)npl * cchunks;
-      const u32x4 xa = x[i0], xb = x[i1];
-      u32x4 ga = xa, gb = xb;
-      if constexpr (BWD) { ga = dy[i0]; gb = dy[i1]; }
-      accum(xa, ga);
-      accum(xb, gb);
+    for (; px + (U - 1) * npl < p1; px += U * npl) {
+      u32x4 xv[U], gv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long i = base + (long)(px + u * npl) * cchunks;
+        xv[u] = x[i];
+        if constexpr (BWD) gv[u] = dy[i]; else gv[u] = xv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) accum(xv[u], gv[u]);
     }
-    if (px < p1) {
-      const long i0 = base + (long)px * cchunks + cq;
-      const u32x4 xa = x[i0];
+    for (; px < p1; px += npl) {
+      const long i = base + (long)px * cchunks;
+      const u32x4 xa = x[i];
       u32x4 ga = xa;
-      if constexpr (BWD) ga = dy[i0];
+      if constexpr (BWD) ga = dy[i];
       accum(xa, ga);
     }
   }
-  // reduce over the pixel lanes (shuffles inside a wave, LDS across waves), then one atomic per (block, channel)
+  // combine the pixel lanes.  Power-of-two cchunks < 64: the lanes of a wave that share cq first (xor shuffles),
+  // then one LDS row per wave; otherwise one LDS row per pixel lane.
+  const bool pre = (cchunks & (cchunks - 1)) == 0 && cchunks < 64;
+  int rows;
+  if (pre) {
 #pragma unroll
-  for (int e = 0; e < V; e++) {
-    const float a = block_sum_by_chunk(s1[e], cchunks, red);
-    const float b = block_sum_by_chunk(s2[e], cchunks, red);
-    if (threadIdx.x < cchunks) {
-      float* dst = sums + ((long)n * Cp + threadIdx.x * V + e) * 2;
-      atomicAdd(dst, a);
-      atomicAdd(dst + 1, b);
+    for (int e = 0; e < V; e++) {
+      for (int o = cchunks; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
     }
+    rows = 4;
+    if ((tid & 63) < cchunks) {
+      const int slot = (tid >> 6) * cchunks + cq;
+#pragma unroll
+      for (int e = 0; e < V; e++) { red[e * STR + slot] = s1[e]; red[(V + e) * STR + slot] = s2[e]; }
+    }
+  } else {
+    rows = npl;
+    if (pl < npl) {
+#pragma unroll
+      for (int e = 0; e < V; e++) { red[e * STR + tid] = s1[e]; red[(V + e) * STR + tid] = s2[e]; }
+    }
+  }
+  __syncthreads();
+  float* dst = part + ((long)n * gridDim.x + blockIdx.x) * Cp * 2;
+  for (int o = tid; o < cchunks * NV; o += 256) {      // o = (cq*V + e)*2 + k: contiguous store
+    const int q = o / NV, j = o % NV, e = j >> 1, k = j & 1;
+    const float* row = red + (k * V + e) * STR + q;
+    float a = 0.f;
+    for (int r = 0; r < rows; r++) a += row[r * cchunks];
+    dst[o] = a;
   }
 }
 
 template <bool BWD>
 static int launch_stats(int dtype, const void* x, const void* dy, const float* scale, const float* shift,
-                        float* sums, int N, int HW, int Cp, int act, float slope, hipStream_t s) {
+                        float* part, int N, int HW, int Cp, int act, float slope, hipStream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(Cp % 8 == 0 && cchunks >= 1 && cchunks <= 256, "nc_stats: unsupported channel count %d", Cp);
-  // sums is accumulated into with atomics: the caller zeroes it (same contract as mt_conv_fwd_stats)
-  // 1024-thread blocks (16 waves per CU in flight for the HBM stream), 8 pixels per thread
-  const int NT = 1024;
-  const int npl = NT / cchunks;
-  int ppb = npl * 8;
-  if (ppb < 64) ppb = 64;
-  // large maps: about one round of 512 resident blocks (fewer block reductions and atomics per byte streamed)
-  const long want = ((long)N * HW + 511) / 512;
-  if (want > ppb) ppb = (int)min((long)HW, (want + npl - 1) / npl * npl);
-  dim3 grid(cdiv(HW, ppb), N);
+  if ((long)N * HW == 0) return 0;
+  int ppb, nparts;
+  stats_geometry(N, HW, cchunks, &ppb, &nparts);
+  dim3 grid(nparts, N);
   if (dtype == MT_BF16)
-    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(NT), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope);
   else
-    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(NT), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, sums, HW, cchunks, ppb, act, slope);
+    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope);
   MT_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mt_nc_stats(int dtype, const void* x, float* sums, int N, int HW, int Cp, mt_stream_t s) {
-  return launch_stats<false>(dtype, x, nullptr, nullptr, nullptr, sums, N, HW, Cp, 0, 0.f, (hipStream_t)s);
+extern "C" int mt_nc_stats(int dtype, const void* x, float* part, int N, int HW, int Cp, mt_stream_t s) {
+  return launch_stats<false>(dtype, x, nullptr, nullptr, nullptr, part, N, HW, Cp, 0, 0.f, (hipStream_t)s);
 }
 extern "C" int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale, const float* shift,
-                               float* sums2, int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
-  return launch_stats<true>(dtype, x, dy, scale, shift, sums2, N, HW, Cp, act, slope, (hipStream_t)s);
+                               float* part, int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
+  return launch_stats<true>(dtype, x, dy, scale, shift, part, N, HW, Cp, act, slope, (hipStream_t)s);
+}
+
+// {sum, sum of squares} of (n, c): the partial rows of image n added in index order
+__device__ __forceinline__ void load_sums(const float* __restrict__ part, int n, int nparts, int Cp, int c, float& a,
+                                          float& b) {
+  const float2* p = (const float2*)part + ((long)n * nparts) * Cp + c;
+  float sa = 0.f, sb = 0.f;
+  for (int k = 0; k < nparts; k++) {
+    const float2 v = p[(long)k * Cp];
+    sa += v.x; sb += v.y;
+  }
+  a = sa; b = sb;
 }
 
 // one block per sample; threads stride over channels
@@ -125,7 +181,7 @@ __global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, c
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* __restrict__ scale, float* __restrict__ shift,
                                      float* __restrict__ mean, float* __restrict__ rstd, int HW, int C, int Cp,
-                                     float eps) {
+                                     float eps, int nparts) {
   const int n = blockIdx.x;
   __shared__ float red[2][4];
   __shared__ float bc[2];
@@ -133,8 +189,9 @@ __global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, c
   if (mode == MT_NORM_LAYER) {
     float a = 0.f, b = 0.f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      a += sums[((long)n * Cp + c) * 2];
-      b += sums[((long)n * Cp + c) * 2 + 1];
+      float ca, cb;
+      load_sums(sums, n, nparts, Cp, c, ca, cb);
+      a += ca; b += cb;
     }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
@@ -160,8 +217,10 @@ __global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, c
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         sc = r * g; sh = b - m * r * g;
       } else {
-        m = sums[i * 2] / (float)HW;
-        float var = sums[i * 2 + 1] / (float)HW - m * m;
+        float ca, cb;
+        load_sums(sums, n, nparts, Cp, c, ca, cb);
+        m = ca / (float)HW;
+        float var = cb / (float)HW - m * m;
         var = var > 0.f ? var : 0.f;
         r = rsqrtf(var + eps);
         float a = 1.f, b = 0.f;
@@ -174,9 +233,10 @@ __global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, c
 }
 extern "C" int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* gamma,
                                 const float* beta, float* scale, float* shift, float* mean, float* rstd, int N,
-                                int HW, int C, int Cp, float eps, mt_stream_t s) {
+                                int HW, int C, int Cp, float eps, int nparts, mt_stream_t s) {
   MT_CHECK(mode != MT_NORM_ADAIN || gb != nullptr, "norm_finalize: adain needs gb");
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, mode, sums, gb, gamma, beta, scale, shift, mean, rstd, HW, C, Cp, eps);
+  MT_CHECK(nparts >= 1, "norm_finalize: nparts %d", nparts);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, mode, sums, gb, gamma, beta, scale, shift, mean, rstd, HW, C, Cp, eps, nparts);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -202,11 +262,10 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const u32x4* __res
 #pragma unroll
   for (int e = 0; e < V; e++) { sc[e] = scale[co + e]; sh[e] = shift[co + e]; }
   const long base = (long)n * HW * cchunks + cq;
-  for (int px = p0 + pl; px < p1; px += npl) {
-    const long i = base + (long)px * cchunks;
+  auto one = [&](long i, const u32x4& xv, const u32x4& rv) {
     float f[V], r[V];
-    Elem<BF16>::unpack(x[i], f);
-    if (res) Elem<BF16>::unpack(res[i], r);
+    Elem<BF16>::unpack(xv, f);
+    if (res) Elem<BF16>::unpack(rv, r);
 #pragma unroll
     for (int e = 0; e < V; e++) {
       float v = act_apply(sc[e] * f[e] + sh[e], act, slope);
@@ -214,6 +273,25 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const u32x4* __res
       f[e] = v;
     }
     __builtin_nontemporal_store(Elem<BF16>::pack(f), &y[i]);      // streaming: written once, read by the next kernel
+  };
+  constexpr int U = 4;                     // independent 16-byte loads in flight per thread (2U with a residual)
+  int px = p0 + pl;
+  for (; px + (U - 1) * npl < p1; px += U * npl) {
+    u32x4 xv[U], rv[U];
+    long idx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      idx[u] = base + (long)(px + u * npl) * cchunks;
+      xv[u] = x[idx[u]];
+      rv[u] = res ? res[idx[u]] : xv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) one(idx[u], xv[u], rv[u]);
+  }
+  for (; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
+    const u32x4 xv = x[i];
+    one(i, xv, res ? res[i] : xv);
   }
 }
 static inline void ew_geometry(int HW, int cchunks, int N, int* threads, int* ppb, dim3* grid) {
@@ -251,8 +329,7 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gb, const float* __restrict__ gamma,
                                          float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
-                                         float* __restrict__ dgb, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta, int HW, int C, int Cp) {
+                                         float* __restrict__ dgb, int HW, int C, int Cp, int nparts) {
   const int n = blockIdx.x;
   __shared__ float red[2][4];
   __shared__ float bc[2];
@@ -261,12 +338,11 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
     float a = 0.f, b = 0.f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const long i = (long)n * Cp + c;
-      const float S1 = sums2[i * 2], S2 = sums2[i * 2 + 1];
+      float S1, S2;
+      load_sums(sums2, n, nparts, Cp, c, S1, S2);
       const float gxh = rstd[i] * (S2 - mean[i] * S1);
       const float g = gamma ? gamma[c] : 1.f;
       a += g * S1; b += g * gxh;
-      if (dgamma) atomicAdd(dgamma + c, gxh);
-      if (dbeta) atomicAdd(dbeta + c, S1);
     }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
@@ -284,7 +360,8 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
     float k1 = 0.f, k2 = 0.f, k3 = 0.f;
     if (c < C) {
       const float m = mean[i], r = rstd[i];
-      const float S1 = sums2[i * 2], S2 = sums2[i * 2 + 1];
+      float S1, S2;
+      load_sums(sums2, n, nparts, Cp, c, S1, S2);
       const float gxh = r * (S2 - m * S1);
       if (mode == MT_NORM_LAYER) {
         const float g = gamma ? gamma[c] : 1.f;
@@ -309,18 +386,37 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
     c1[i] = k1; c2[i] = k2; c3[i] = k3;
   }
 }
+// LayerNorm affine gradients: dgamma[c] = sum_n sum(g*xh)(n,c), dbeta[c] = sum_n sum(g)(n,c), images added in index
+// order (one thread per channel; reproducible)
+__global__ void ln_param_grad_kernel(const float* __restrict__ sums2, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int N, int C, int Cp, int nparts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  for (int n = 0; n < N; n++) {
+    float S1, S2;
+    load_sums(sums2, n, nparts, Cp, c, S1, S2);
+    const long i = (long)n * Cp + c;
+    dg += rstd[i] * (S2 - mean[i] * S1);
+    db += S1;
+  }
+  if (dgamma) dgamma[c] = dg;
+  if (dbeta) dbeta[c] = db;
+}
 extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const float* rstd,
                                     const float* gb, const float* gamma, float* c1, float* c2, float* c3,
                                     float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,
-                                    mt_stream_t st) {
+                                    int nparts, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_finalize: adain needs gb/dgb");
-  if (mode == MT_NORM_LAYER) {
-    if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("memset"); return 2; }
-    if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * C, s) != hipSuccess) { mt_set_error("memset"); return 2; }
-  }
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, dgamma, dbeta, HW, C, Cp);
+  MT_CHECK(nparts >= 1, "norm_bwd_finalize: nparts %d", nparts);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, HW, C, Cp, nparts);
   MT_LAUNCH_CHECK();
+  if (mode == MT_NORM_LAYER && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, sums2, mean, rstd, dgamma, dbeta, N, C, Cp, nparts);
+    MT_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -346,17 +442,34 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const u32x4* __rest
     k1[e] = c1[co + e]; k2[e] = c2[co + e]; k3[e] = c3[co + e];
   }
   const long base = (long)n * HW * cchunks + cq;
-  for (int px = p0 + pl; px < p1; px += npl) {
-    const long i = base + (long)px * cchunks;
+  auto one = [&](long i, const u32x4& xv, const u32x4& gv) {
     float f[V], g[V];
-    Elem<BF16>::unpack(x[i], f);
-    Elem<BF16>::unpack(dy[i], g);
+    Elem<BF16>::unpack(xv, f);
+    Elem<BF16>::unpack(gv, g);
 #pragma unroll
     for (int e = 0; e < V; e++) {
       const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
       f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
     }
     __builtin_nontemporal_store(Elem<BF16>::pack(f), &dx[i]);
+  };
+  constexpr int U = 4;
+  int px = p0 + pl;
+  for (; px + (U - 1) * npl < p1; px += U * npl) {
+    u32x4 xv[U], gv[U];
+    long idx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      idx[u] = base + (long)(px + u * npl) * cchunks;
+      xv[u] = x[idx[u]];
+      gv[u] = dy[idx[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) one(idx[u], xv[u], gv[u]);
+  }
+  for (; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
+    one(i, x[i], dy[i]);
   }
 }
 extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
@@ -384,14 +497,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    float momentum, float eps, int training, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd, int N,
-                                   int HW, int C, int Cp) {
+                                   int HW, int C, int Cp, int nparts) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   float m = 0.f, r = 0.f, sc = 0.f, sh = 0.f;
   if (c < C) {
     if (training) {
       float s1 = 0.f, s2 = 0.f;
-      for (int n = 0; n < N; n++) { s1 += sums[((long)n * Cp + c) * 2]; s2 += sums[((long)n * Cp + c) * 2 + 1]; }
+      for (int n = 0; n < N; n++) {
+        float a, b;
+        load_sums(sums, n, nparts, Cp, c, a, b);
+        s1 += a; s2 += b;
+      }
       const float cnt = (float)N * (float)HW;
       m = s1 / cnt;
       float var = s2 / cnt - m * m;
@@ -414,10 +531,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
 }
 extern "C" int mt_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float momentum, float eps, int training, float* scale, float* shift,
-                              float* mean, float* rstd, int N, int HW, int C, int Cp, mt_stream_t s) {
+                              float* mean, float* rstd, int N, int HW, int C, int Cp, int nparts, mt_stream_t s) {
   MT_CHECK(running_mean != nullptr && running_var != nullptr, "bn_finalize: running statistics buffers are required");
   MT_CHECK(!training || sums != nullptr, "bn_finalize: training mode needs the batch sums");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, N, HW, C, Cp);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, N, HW, C, Cp, nparts);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -426,13 +543,17 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums2, const fl
                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                        float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int training, int N, int HW,
-                                       int C, int Cp) {
+                                       int C, int Cp, int nparts) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   float k1 = 0.f, k2 = 0.f, k3 = 0.f;
   if (c < C) {
     float S1 = 0.f, S2 = 0.f;
-    for (int n = 0; n < N; n++) { S1 += sums2[((long)n * Cp + c) * 2]; S2 += sums2[((long)n * Cp + c) * 2 + 1]; }
+    for (int n = 0; n < N; n++) {
+      float a, b;
+      load_sums(sums2, n, nparts, Cp, c, a, b);
+      S1 += a; S2 += b;
+    }
     const float m = mean[c], r = rstd[c];
     const float gxh = r * (S2 - m * S1);
     const float g = gamma ? gamma[c] : 1.f;
@@ -452,8 +573,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums2, const fl
 }
 extern "C" int mt_bn_bwd_finalize(const float* sums2, const float* mean, const float* rstd, const float* gamma, float* c1,
                                   float* c2, float* c3, float* dgamma, float* dbeta, int training, int N, int HW, int C,
-                                  int Cp, mt_stream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums2, mean, rstd, gamma, c1, c2, c3, dgamma, dbeta, training, N, HW, C, Cp);
+                                  int Cp, int nparts, mt_stream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, (hipStream_t)s, sums2, mean, rstd, gamma, c1, c2, c3, dgamma, dbeta, training, N, HW, C, Cp, nparts);
   MT_LAUNCH_CHECK();
   return 0;
 }

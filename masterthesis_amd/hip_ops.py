@@ -272,6 +272,18 @@ def repack_params(params):
 # --------------------------------------------------------------------------------------
 _KTIMER = {"match": None, "events": []}
 _FUSE_WGRAD_ACC = [False]
+_DETERMINISTIC = [os.environ.get("MT_DETERMINISTIC", "0") == "1"]
+
+
+def set_deterministic(on):
+    """Bit-reproducible runs: every reduction whose summation order depends on scheduling (the fp32 atomics of the
+    fused convolution-statistics epilogue, of the loss reductions and of the thin 1x1 weight gradient) is replaced by
+    its fixed-order variant.  Costs one extra statistics pass per normalised convolution.  Also MT_DETERMINISTIC=1."""
+    _DETERMINISTIC[0] = bool(on)
+
+
+def deterministic():
+    return _DETERMINISTIC[0]
 
 
 def set_fused_grad_accumulation(on):
@@ -367,7 +379,9 @@ class _Conv(torch.autograd.Function):
         y = new_act(N, Co, ho.value, wo.value, dt, x.device)
         pack = _get_pack(owner, weight, desc, L.PACK_FWD)
         b = None if bias is None else _f32c(bias.detach())
-        # normalisation statistics of the output are accumulated (atomics) in the GEMM epilogue
+        # normalisation statistics of the output are accumulated (atomics) in the GEMM epilogue where the shape allows
+        # it; otherwise (and in deterministic mode) the norm layer runs its own reproducible statistics pass
+        want_stats = bool(want_stats and not _DETERMINISTIC[0] and lib.mt_conv_fwd_stats_fused(C.byref(desc)))
         sums = _zero_stats((N, padc(Co), 2), x.device) if want_stats else None
         timed = _KTIMER["match"] is not None and _KTIMER["match"](desc)
         if timed:
@@ -394,8 +408,9 @@ class _Conv(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.has_bias = bias is not None and bias_grad
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
-        if want_stats:
-            ctx.mark_non_differentiable(sums)
+        if cfg[7]:                         # the caller asked for statistics: always a pair (sums may be None)
+            if sums is not None:
+                ctx.mark_non_differentiable(sums)
             return y, sums
         return y
 
@@ -568,10 +583,12 @@ class _Norm(torch.autograd.Function):
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
+        nparts = 1
         if bn is not None and not bn[3]:
             sums = None                                  # eval mode: running statistics, no pass over x
         elif sums is None:
-            sums = _zero_stats((N, Cp, 2), dev)
+            nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
+            sums = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)     # every element is written
             L.check(lib.mt_nc_stats(mt, _ptr(x), _ptr(sums), N, HW, Cp, _stream()), "mt_nc_stats")
         elif tuple(sums.shape) != (N, Cp, 2):
             raise RuntimeError(f"norm: precomputed statistics have shape {tuple(sums.shape)}, expected {(N, Cp, 2)}")
@@ -585,10 +602,10 @@ class _Norm(torch.autograd.Function):
             rm, rv, momentum, training = bn
             L.check(lib.mt_bn_finalize(_ptr(sums), _ptr(gm), _ptr(bt), _ptr(rm), _ptr(rv), float(momentum), eps,
                                        int(training), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc,
-                                       Cp, _stream()), "mt_bn_finalize")
+                                       Cp, nparts, _stream()), "mt_bn_finalize")
         else:
             L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
-                                         _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, _stream()),
+                                         _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, nparts, _stream()),
                     "mt_norm_finalize")
         r = None if res is None else canon(res)
         y = new_act(N, Cc, H, W, x.dtype, dev)
@@ -609,7 +626,8 @@ class _Norm(torch.autograd.Function):
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
-        sums2 = _zero_stats((N, Cp, 2), dev)
+        nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
+        sums2 = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)
         L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
                                     slope, _stream()), "mt_nc_stats_bwd")
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
@@ -621,11 +639,11 @@ class _Norm(torch.autograd.Function):
         if mode == L.NORM_BATCH:
             L.check(lib.mt_bn_bwd_finalize(_ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gm), _ptr(cc[0]), _ptr(cc[1]),
                                            _ptr(cc[2]), _ptr(dgamma), _ptr(dbeta), int(ctx.cfg[4][3]), N, HW, Cc, Cp,
-                                           _stream()), "mt_bn_bwd_finalize")
+                                           nparts, _stream()), "mt_bn_bwd_finalize")
         else:
             L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
                                              _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
-                                             _ptr(dbeta), N, HW, Cc, Cp, _stream()), "mt_norm_bwd_finalize")
+                                             _ptr(dbeta), N, HW, Cc, Cp, nparts, _stream()), "mt_norm_bwd_finalize")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cc, H, W, x.dtype, dev)

@@ -211,12 +211,15 @@ class AdaINResnetBlock(nn.Module):
         self.dropout = Dropout(0.5) if dropout else nn.Identity()
 
     def forward(self, x, z):
+        # the reference evaluates norm.fc(z) at both norm sites (blocks.py:158-164): same weights, same input, so
+        # one projection serves both (its gradient is the sum of the two sites')
+        gb = self.norm.project(z)
         y, sums = self.conv1(x, want_stats=True)
-        h = self.norm(y, z, act=self.act, sums=sums)
+        h = self.norm(y, z, act=self.act, sums=sums, gb=gb)
         y, sums = self.conv2(h, want_stats=True)
         if isinstance(self.dropout, Dropout) and self.training:
-            return ops.add(self.dropout(self.norm(y, z, sums=sums)), x)     # (the add cannot ride on the norm pass)
-        return self.norm(y, z, res=x, sums=sums)
+            return ops.add(self.dropout(self.norm(y, z, sums=sums, gb=gb)), x)     # (the add cannot ride on the norm pass)
+        return self.norm(y, z, res=x, sums=sums, gb=gb)
 
 
 def _expand_planes(v, ref):

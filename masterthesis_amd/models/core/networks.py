@@ -34,10 +34,17 @@ class ContentEncoder(nn.Module):
         self.model = nn.Sequential(*layers)
         self.output_dim = dim
 
-    def forward(self, x):
-        for layer in self.model:
+    def features(self, x):
+        """everything in front of the GaussianNoiseLayer: a deterministic function of (x, weights)"""
+        for layer in self.model[:-1]:
             x = layer(x)
         return x
+
+    def add_noise(self, h):
+        return self.model[-1](h)
+
+    def forward(self, x):
+        return self.add_noise(self.features(x))
 
 
 class StyleEncoder(nn.Module):
@@ -89,13 +96,18 @@ class ReparameterizedStyleEncoder(nn.Module):
         eps = random_source().eps(tuple(mu.shape), mu.device)
         return ops.reparameterize(mu, logvar, eps)
 
-    def forward(self, x, c):
+    def moments(self, x, c):
+        """(mu, logvar): the deterministic part of the encoder (everything in front of the eps draw)"""
         h = ops.cat_class_planes(x, c)
         for layer in self.model[:-2]:
             h = layer(h)
         flat = ops.global_avg_pool(ops.activation(h, self.act))
         mu = ops.linear(flat, self.fc.weight, self.fc.bias)
         logvar = ops.linear(flat, self.fcVar.weight, self.fcVar.bias)
+        return mu, logvar
+
+    def forward(self, x, c):
+        mu, logvar = self.moments(x, c)
         return self.reparameterize(mu, logvar), mu, logvar
 
 

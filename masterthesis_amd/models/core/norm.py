@@ -33,6 +33,10 @@ class AdaptiveInstanceNorm(nn.Module):
         self.num_features = num_features
         self.fc = nn.Linear(style_dim, num_features * 2)
 
-    def forward(self, x, s, act=None, res=None, sums=None):
-        h = ops.linear(s, self.fc.weight, self.fc.bias)
+    def project(self, s):
+        """[w, b] = fc(s); a block that normalises twice with the same style (blocks.py:152-164) projects once"""
+        return ops.linear(s, self.fc.weight, self.fc.bias)
+
+    def forward(self, x, s, act=None, res=None, sums=None, gb=None):
+        h = self.project(s) if gb is None else gb
         return ops.adain_act(x, h, act=act, res=res, sums=sums)

@@ -19,6 +19,7 @@ MI355X-first execution choices (all trajectory-identical to the reference, SURVE
    (adain_model.py:313-314) so its gradient is scaled by world_size to stay equal to one process at
    the global batch.
 """
+import os
 import time
 
 import torch
@@ -84,6 +85,37 @@ class TranslationModel(Model):
     def _encode_style(self, img, c):
         out = self.model.style_encoder(img, c)
         return out if self.reparam else (out, None, None)
+
+    # ---- encoder passes shared by the discriminator update and phase 3 ---------------------------------
+    def _share_encoders(self):
+        """The reference encodes ``img`` in update_discriminator (adain_model.py:153-156) and again at the top of
+        backward_generator (244-247) with the SAME encoder weights (only the discriminators step in between): up to the
+        random draws -- content noise, reparameterisation eps -- the two passes compute identical numbers.  Here the
+        deterministic part (ContentEncoder.features, the style encoder's moments) runs once per step, with its autograd
+        graph, and each phase applies its own fresh draws (in the reference's draw order).  Not with BatchNorm in the
+        encoders (every forward call updates the running statistics) and not outside training mode."""
+        a = self.args
+        Ec, Es = self.model.content_encoder, self.model.style_encoder
+        return (Ec.training and Es.training and getattr(a, "enc_norm", "instance") != "batch"
+                and hasattr(Ec, "features") and os.environ.get("MT_NO_ENCODER_SHARING", "0") != "1")
+
+    def _encode_shared(self, img, c_org):
+        Ec, Es = self.model.content_encoder, self.model.style_encoder
+        h = Ec.features(img)
+        if self.reparam:
+            return h, Es.moments(img, c_org)
+        return h, (Es(img, c_org),)
+
+    def _draw_from_shared(self, shared, detach):
+        """(z_c, z_s, mu, logvar) from the shared deterministic part with fresh draws"""
+        h, st = shared
+        if detach:
+            h, st = h.detach(), tuple(t.detach() for t in st)
+        z_c = self.model.content_encoder.add_noise(h)
+        if self.reparam:
+            mu, logvar = st
+            return z_c, self.model.style_encoder.reparameterize(mu, logvar), mu, logvar
+        return z_c, st[0], None, None
 
     def _translate(self, contents, styles, classes, per_call=None):
         """Several translations in one decoder call.  ``per_call``: how many of the parts the reference feeds to ONE
@@ -161,9 +193,14 @@ class TranslationModel(Model):
         self._finish_deferred()
         B = self.args.batch_size
         cls_a, cls_b = torch.split(c_org, B, dim=0)
+        self._shared = self._encode_shared(img, c_org) if self._share_encoders() else None
         with torch.no_grad():
-            z_ca, z_cb = torch.split(self.model.content_encoder(img), B, dim=0)
-            z_s, _, _ = self._encode_style(img, c_org)
+            if self._shared is not None:
+                z_c, z_s, _, _ = self._draw_from_shared(self._shared, detach=True)
+            else:
+                z_c = self.model.content_encoder(img)
+                z_s, _, _ = self._encode_style(img, c_org)
+            z_ca, z_cb = torch.split(z_c, B, dim=0)
             z_sa, z_sb = torch.split(z_s, B, dim=0)
             z_sr = self.get_z_random(B, self.args.latent_dim)
             # all four translations in ONE decoder call (per-sample AdaIN / LayerNorm: identical outputs, half
@@ -265,9 +302,14 @@ class TranslationModel(Model):
     def backward_generator(self, img, c_org):
         a, B = self.args, self.args.batch_size
         cls_a, cls_b = torch.split(c_org, B, dim=0)
-        z_c = self.model.content_encoder(img)
+        shared = self.__dict__.pop("_shared", None)
+        if shared is not None:
+            z_c, z_s, mu, logvar = self._draw_from_shared(shared, detach=False)
+            del shared
+        else:
+            z_c = self.model.content_encoder(img)
+            z_s, mu, logvar = self._encode_style(img, c_org)
         z_ca, z_cb = torch.split(z_c, B, dim=0)
-        z_s, mu, logvar = self._encode_style(img, c_org)
         z_sa, z_sb = torch.split(z_s, B, dim=0)
         img_ba, img_aa, img_ab, img_bb = self._translate((z_cb, z_ca, z_ca, z_cb), (z_sa, z_sa, z_sb, z_sb),
                                                          (cls_a, cls_a, cls_b, cls_b), per_call=2)    # one 4B-image decoder call
