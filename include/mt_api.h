@@ -134,7 +134,8 @@ int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale
                     const float* shift, float* part2, int N, int HW, int Cp, int act,
                     float slope, mt_stream_t s);
 /* coefficients for dx = c1*g + c2 + c3*x; plus parameter gradients:
- * ADAIN: dgb [N][2C]; LAYER: dgamma, dbeta [C]. */
+ * ADAIN: dgb [N][2C]; LAYER: dgamma, dbeta [C], with dgb a caller-provided [N][2][C] scratch (per-image terms,
+ * added over the images in index order). */
 int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const float* rstd,
                          const float* gb, const float* gamma, float* c1, float* c2, float* c3,
                          float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,

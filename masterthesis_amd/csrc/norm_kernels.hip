@@ -176,23 +176,62 @@ __device__ __forceinline__ void load_sums(const float* __restrict__ part, int n,
   a = sa; b = sb;
 }
 
+// Per-image totals of the partial rows in LDS: tot[c] = {sum, sum2} of (n, c).  FIN_T threads; with G = FIN_T / Cp
+// thread groups (Cp <= FIN_T) group g adds rows g, g+G, ... and the groups are then added in index order -- a fixed
+// order, independent of scheduling.  Cp <= MT_FIN_MAXC.
+#define FIN_T 1024
+#define MT_FIN_MAXC 2048
+__device__ __forceinline__ void combine_parts(const float* __restrict__ part, int n, int nparts, int Cp,
+                                              float2* __restrict__ tot, float2* __restrict__ scratch) {
+  const int t = threadIdx.x;
+  const float2* p = (const float2*)part + ((long)n * nparts) * Cp;
+  if (nparts == 1) {
+    for (int c = t; c < Cp; c += FIN_T) tot[c] = p[c];
+  } else if (Cp <= FIN_T) {
+    const int G = FIN_T / Cp;
+    const int c = t % Cp, g = t / Cp;
+    float sa = 0.f, sb = 0.f;
+    if (g < G) {
+#pragma unroll 4
+      for (int k = g; k < nparts; k += G) {
+        const float2 v = p[(long)k * Cp + c];
+        sa += v.x; sb += v.y;
+      }
+    }
+    scratch[t] = make_float2(sa, sb);
+    __syncthreads();
+    if (t < Cp) {
+      float ta = 0.f, tb = 0.f;
+      for (int j = 0; j < G; j++) { const float2 v = scratch[t + j * Cp]; ta += v.x; tb += v.y; }
+      tot[t] = make_float2(ta, tb);
+    }
+  } else {
+    for (int c = t; c < Cp; c += FIN_T) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < nparts; k++) { const float2 v = p[(long)k * Cp + c]; sa += v.x; sb += v.y; }
+      tot[c] = make_float2(sa, sb);
+    }
+  }
+  __syncthreads();
+}
+
 // one block per sample; threads stride over channels
-__global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, const float* __restrict__ gb,
+__global__ __launch_bounds__(FIN_T) void norm_finalize_kernel(int mode, const float* __restrict__ sums, const float* __restrict__ gb,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* __restrict__ scale, float* __restrict__ shift,
                                      float* __restrict__ mean, float* __restrict__ rstd, int HW, int C, int Cp,
                                      float eps, int nparts) {
   const int n = blockIdx.x;
-  __shared__ float red[2][4];
+  __shared__ float red[2][FIN_T / 64];
   __shared__ float bc[2];
+  __shared__ float2 tot[MT_FIN_MAXC];
+  __shared__ float2 scratch[FIN_T];
+  combine_parts(sums, n, nparts, Cp, tot, scratch);
   float lmean = 0.f, lrstd = 0.f;
   if (mode == MT_NORM_LAYER) {
     float a = 0.f, b = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      float ca, cb;
-      load_sums(sums, n, nparts, Cp, c, ca, cb);
-      a += ca; b += cb;
-    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { a += tot[c].x; b += tot[c].y; }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
@@ -217,8 +256,7 @@ __global__ void norm_finalize_kernel(int mode, const float* __restrict__ sums, c
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         sc = r * g; sh = b - m * r * g;
       } else {
-        float ca, cb;
-        load_sums(sums, n, nparts, Cp, c, ca, cb);
+        const float ca = tot[c].x, cb = tot[c].y;
         m = ca / (float)HW;
         float var = cb / (float)HW - m * m;
         var = var > 0.f ? var : 0.f;
@@ -235,8 +273,8 @@ extern "C" int mt_norm_finalize(int mode, const float* sums, const float* gb, co
                                 const float* beta, float* scale, float* shift, float* mean, float* rstd, int N,
                                 int HW, int C, int Cp, float eps, int nparts, mt_stream_t s) {
   MT_CHECK(mode != MT_NORM_ADAIN || gb != nullptr, "norm_finalize: adain needs gb");
-  MT_CHECK(nparts >= 1, "norm_finalize: nparts %d", nparts);
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, mode, sums, gb, gamma, beta, scale, shift, mean, rstd, HW, C, Cp, eps, nparts);
+  MT_CHECK(nparts >= 1 && Cp <= MT_FIN_MAXC, "norm_finalize: nparts %d, Cp %d", nparts, Cp);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(FIN_T), 0, (hipStream_t)s, mode, sums, gb, gamma, beta, scale, shift, mean, rstd, HW, C, Cp, eps, nparts);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -325,24 +363,27 @@ extern "C" int mt_scale_shift_act(int dtype, const void* x, const float* scale, 
 //   sum g*xh = r*(S2 - m*S1)
 //   INSTANCE/ADAIN: dx = r*a*(g - S1/HW - xh * sum(g*xh)/HW)
 //   LAYER         : dx = r*(a*g - A/(C*HW) - xh * B/(C*HW)),  A = sum_c a_c*S1_c, B = sum_c a_c*sum(g*xh)_c
-__global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sums2,
+__global__ __launch_bounds__(FIN_T) void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sums2,
                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gb, const float* __restrict__ gamma,
                                          float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3,
                                          float* __restrict__ dgb, int HW, int C, int Cp, int nparts) {
   const int n = blockIdx.x;
-  __shared__ float red[2][4];
+  __shared__ float red[2][FIN_T / 64];
   __shared__ float bc[2];
+  __shared__ float2 tot[MT_FIN_MAXC];
+  __shared__ float2 scratch[FIN_T];
+  combine_parts(sums2, n, nparts, Cp, tot, scratch);
   float LA = 0.f, LB = 0.f;
   if (mode == MT_NORM_LAYER) {
     float a = 0.f, b = 0.f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const long i = (long)n * Cp + c;
-      float S1, S2;
-      load_sums(sums2, n, nparts, Cp, c, S1, S2);
+      const float S1 = tot[c].x, S2 = tot[c].y;
       const float gxh = rstd[i] * (S2 - mean[i] * S1);
       const float g = gamma ? gamma[c] : 1.f;
       a += g * S1; b += g * gxh;
+      if (dgb) { dgb[(long)n * 2 * C + c] = gxh; dgb[(long)n * 2 * C + C + c] = S1; }   // per-image terms of dgamma, dbeta
     }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
@@ -360,8 +401,7 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
     float k1 = 0.f, k2 = 0.f, k3 = 0.f;
     if (c < C) {
       const float m = mean[i], r = rstd[i];
-      float S1, S2;
-      load_sums(sums2, n, nparts, Cp, c, S1, S2);
+      const float S1 = tot[c].x, S2 = tot[c].y;
       const float gxh = r * (S2 - m * S1);
       if (mode == MT_NORM_LAYER) {
         const float g = gamma ? gamma[c] : 1.f;
@@ -386,21 +426,14 @@ __global__ void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sum
     c1[i] = k1; c2[i] = k2; c3[i] = k3;
   }
 }
-// LayerNorm affine gradients: dgamma[c] = sum_n sum(g*xh)(n,c), dbeta[c] = sum_n sum(g)(n,c), images added in index
-// order (one thread per channel; reproducible)
-__global__ void ln_param_grad_kernel(const float* __restrict__ sums2, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int N, int C, int Cp, int nparts) {
+// LayerNorm affine gradients from the per-image terms the finalize kernel left in pg [N][2][C]:
+// dgamma[c] = sum_n pg[n][0][c], dbeta[c] = sum_n pg[n][1][c], images added in index order (reproducible)
+__global__ void ln_param_grad_kernel(const float* __restrict__ pg, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int N, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float dg = 0.f, db = 0.f;
-  for (int n = 0; n < N; n++) {
-    float S1, S2;
-    load_sums(sums2, n, nparts, Cp, c, S1, S2);
-    const long i = (long)n * Cp + c;
-    dg += rstd[i] * (S2 - mean[i] * S1);
-    db += S1;
-  }
+  for (int n = 0; n < N; n++) { dg += pg[(long)n * 2 * C + c]; db += pg[(long)n * 2 * C + C + c]; }
   if (dgamma) dgamma[c] = dg;
   if (dbeta) dbeta[c] = db;
 }
@@ -410,83 +443,15 @@ extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* m
                                     int nparts, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_finalize: adain needs gb/dgb");
-  MT_CHECK(nparts >= 1, "norm_bwd_finalize: nparts %d", nparts);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, HW, C, Cp, nparts);
+  MT_CHECK(mode != MT_NORM_LAYER || !(dgamma || dbeta) || dgb != nullptr,
+           "norm_bwd_finalize: layer norm with affine gradients needs the [N][2][C] scratch in dgb");
+  MT_CHECK(nparts >= 1 && Cp <= MT_FIN_MAXC, "norm_bwd_finalize: nparts %d, Cp %d", nparts, Cp);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(FIN_T), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, HW, C, Cp, nparts);
   MT_LAUNCH_CHECK();
   if (mode == MT_NORM_LAYER && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, sums2, mean, rstd, dgamma, dbeta, N, C, Cp, nparts);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dgb, dgamma, dbeta, N, C);
     MT_LAUNCH_CHECK();
   }
-  return 0;
-}
-
-template <bool BF16>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
-                                                             const float* __restrict__ scale,
-                                                             const float* __restrict__ shift,
-                                                             const float* __restrict__ c1, const float* __restrict__ c2,
-                                                             const float* __restrict__ c3, u32x4* __restrict__ dx, int HW,
-                                                             int cchunks, int pix_per_block, int act, float slope) {
-  constexpr int V = Elem<BF16>::V;
-  const int n = blockIdx.y;
-  const int cq = threadIdx.x % cchunks;
-  const int pl = threadIdx.x / cchunks;
-  const int npl = blockDim.x / cchunks;
-  const int p0 = blockIdx.x * pix_per_block;
-  const int p1 = min(HW, p0 + pix_per_block);
-  float sc[V], sh[V], k1[V], k2[V], k3[V];
-  const long co = ((long)n * cchunks + cq) * V;
-#pragma unroll
-  for (int e = 0; e < V; e++) {
-    sc[e] = scale[co + e]; sh[e] = shift[co + e];
-    k1[e] = c1[co + e]; k2[e] = c2[co + e]; k3[e] = c3[co + e];
-  }
-  const long base = (long)n * HW * cchunks + cq;
-  auto one = [&](long i, const u32x4& xv, const u32x4& gv) {
-    float f[V], g[V];
-    Elem<BF16>::unpack(xv, f);
-    Elem<BF16>::unpack(gv, g);
-#pragma unroll
-    for (int e = 0; e < V; e++) {
-      const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
-      f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
-    }
-    __builtin_nontemporal_store(Elem<BF16>::pack(f), &dx[i]);
-  };
-  constexpr int U = 4;
-  int px = p0 + pl;
-  for (; px + (U - 1) * npl < p1; px += U * npl) {
-    u32x4 xv[U], gv[U];
-    long idx[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      idx[u] = base + (long)(px + u * npl) * cchunks;
-      xv[u] = x[idx[u]];
-      gv[u] = dy[idx[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) one(idx[u], xv[u], gv[u]);
-  }
-  for (; px < p1; px += npl) {
-    const long i = base + (long)px * cchunks;
-    one(i, x[i], dy[i]);
-  }
-}
-extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
-                                 const float* shift, const float* c1, const float* c2, const float* c3, void* dx,
-                                 int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
-  const int V = dtype == MT_BF16 ? 8 : 4;
-  const int cchunks = Cp / V;
-  MT_CHECK(cchunks >= 1 && cchunks <= 256, "norm_bwd_apply: unsupported channel count %d", Cp);
-  if ((long)N * HW == 0) return 0;
-  int threads, ppb;
-  dim3 grid;
-  ew_geometry(HW, cchunks, N, &threads, &ppb, &grid);
-  if (dtype == MT_BF16)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
-  else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
-  MT_LAUNCH_CHECK();
   return 0;
 }
 

@@ -636,6 +636,8 @@ class _Norm(torch.autograd.Function):
         if mode in (L.NORM_LAYER, L.NORM_BATCH) and gm is not None:
             dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+            if mode == L.NORM_LAYER:
+                dgb = torch.empty((N, 2, Cc), dtype=torch.float32, device=dev)      # per-image terms of dgamma / dbeta
         if mode == L.NORM_BATCH:
             L.check(lib.mt_bn_bwd_finalize(_ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gm), _ptr(cc[0]), _ptr(cc[1]),
                                            _ptr(cc[2]), _ptr(dgamma), _ptr(dbeta), int(ctx.cfg[4][3]), N, HW, Cc, Cp,
@@ -655,7 +657,7 @@ class _Norm(torch.autograd.Function):
             dgamma = dgamma.view(gshape)
             dbeta = dbeta.view(bshape)
         dres = dy if ctx.needs_input_grad[4] else None
-        return dx, dgb, dgamma, dbeta, dres, None, None
+        return dx, (dgb if mode == L.NORM_ADAIN else None), dgamma, dbeta, dres, None, None
 
 
 def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
