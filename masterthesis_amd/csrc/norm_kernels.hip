@@ -455,6 +455,76 @@ extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* m
   return 0;
 }
 
+template <bool BF16>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ c1, const float* __restrict__ c2,
+                                                             const float* __restrict__ c3, u32x4* __restrict__ dx, int HW,
+                                                             int cchunks, int pix_per_block, int act, float slope) {
+  constexpr int V = Elem<BF16>::V;
+  const int n = blockIdx.y;
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float sc[V], sh[V], k1[V], k2[V], k3[V];
+  const long co = ((long)n * cchunks + cq) * V;
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    sc[e] = scale[co + e]; sh[e] = shift[co + e];
+    k1[e] = c1[co + e]; k2[e] = c2[co + e]; k3[e] = c3[co + e];
+  }
+  const long base = (long)n * HW * cchunks + cq;
+  auto one = [&](long i, const u32x4& xv, const u32x4& gv) {
+    float f[V], g[V];
+    Elem<BF16>::unpack(xv, f);
+    Elem<BF16>::unpack(gv, g);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float gg = g[e] * act_grad_z(sc[e] * f[e] + sh[e], act, slope);
+      f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
+    }
+    __builtin_nontemporal_store(Elem<BF16>::pack(f), &dx[i]);
+  };
+  constexpr int U = 4;
+  int px = p0 + pl;
+  for (; px + (U - 1) * npl < p1; px += U * npl) {
+    u32x4 xv[U], gv[U];
+    long idx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      idx[u] = base + (long)(px + u * npl) * cchunks;
+      xv[u] = x[idx[u]];
+      gv[u] = dy[idx[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) one(idx[u], xv[u], gv[u]);
+  }
+  for (; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
+    one(i, x[i], dy[i]);
+  }
+}
+extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
+                                 const float* shift, const float* c1, const float* c2, const float* c3, void* dx,
+                                 int N, int HW, int Cp, int act, float slope, mt_stream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  MT_CHECK(cchunks >= 1 && cchunks <= 256, "norm_bwd_apply: unsupported channel count %d", Cp);
+  if ((long)N * HW == 0) return 0;
+  int threads, ppb;
+  dim3 grid;
+  ew_geometry(HW, cchunks, N, &threads, &ppb, &grid);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
+  else
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)dy, (const u32x4*)x, scale, shift, c1, c2, c3, (u32x4*)dx, HW, cchunks, ppb, act, slope);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- BatchNorm2d (--enc_norm / --dec_norm / --dis_norm batch; functions.py:14-15: affine, running statistics) ---------------
 // Same four passes as the other norms: the per-(image, channel) sums are pooled over the batch here, the per-(n, c)
 // coefficient arrays are filled with the per-channel values so the elementwise kernels are shared.
