@@ -165,11 +165,19 @@ int mt_add(int dtype, const void* a, const void* b, void* y, size_t n, mt_stream
 /* ... or generated on device: Philox4x32-10 + Box-Muller, N(0,1), counter = element index. */
 int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t seed,
                           uint64_t offset, mt_stream_t s);
+/* The same draw from a DEVICE-resident generator state {uint64 seed, uint64 draw counter}: nothing random travels in
+ * the launch arguments, so the call can sit in a captured hipGraph and still produce fresh noise on every replay (draw
+ * k uses Philox counters [k << 40, (k+1) << 40)).  mt_rng_advance(state) increments the draw counter in stream order;
+ * call it after each draw. */
+int mt_gaussian_noise_add_dev(int dtype, const void* x, void* y, size_t n, const uint64_t* dev_state, mt_stream_t s);
+int mt_rng_advance(uint64_t* dev_state, mt_stream_t s);
 /* nn.Dropout(0.5) (--use_dropout; blocks.py:133-134, 153-165, 192-207): mask ~ Bernoulli(keep) in the activation layout
  * [npix][Cp] (pad channels 0; Philox4x32-10, counter = element index), and y = a * b * scale (forward: x * mask / keep,
  * backward: dy * mask / keep). */
 int mt_bernoulli_mask(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed, uint64_t offset,
                       mt_stream_t s);
+int mt_bernoulli_mask_dev(int dtype, void* mask, size_t npix, int C, int Cp, float keep, const uint64_t* dev_state,
+                          mt_stream_t s);
 int mt_mul_scale(int dtype, const void* a, const void* b, void* y, size_t n, float scale, mt_stream_t s);
 int mt_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
@@ -254,6 +262,12 @@ int mt_kl_bwd(const float* mu, const float* logvar, const float* gscale, float* 
  * [p0,g0,m0,v0,p1,...]; sizes: device array of element counts; L2-coupled weight decay. */
 int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float lr,
                   float beta1, float beta2, float eps, float wd, int step, mt_stream_t s);
+/* The same update with the per-step scalars on the device: dev_state = 16 bytes {float lr; int32 step; float bc1; float
+ * bc2_sqrt}.  The call first ticks the record (step += 1, bias corrections recomputed in double precision), then updates
+ * with it -- no launch argument changes between steps, so the pair is hipGraph-capturable.  The caller initialises
+ * lr and step (bc* are outputs) and rewrites lr when the schedule changes it. */
+int mt_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float beta1, float beta2,
+                      float eps, float wd, void* dev_state, mt_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,9 @@ SIGNATURES = {
     "mt_add": (_i, [_i, _p, _p, _p, _z, _p]),
     "mt_gaussian_noise_add": (_i, [_i, _p, _p, _z, _u64, _u64, _p]),
     "mt_bernoulli_mask": (_i, [_i, _p, _z, _i, _i, _f, _u64, _u64, _p]),
+    "mt_gaussian_noise_add_dev": (_i, [_i, _p, _p, _z, _p, _p]),
+    "mt_rng_advance": (_i, [_p, _p]),
+    "mt_bernoulli_mask_dev": (_i, [_i, _p, _z, _i, _i, _f, _p, _p]),
     "mt_mul_scale": (_i, [_i, _p, _p, _p, _z, _f, _p]),
     "mt_avgpool2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_avgpool2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
@@ -101,6 +104,7 @@ SIGNATURES = {
     "mt_kl_fwd": (_i, [_p, _p, _p, _z, _p]),
     "mt_kl_bwd": (_i, [_p, _p, _p, _p, _p, _z, _p]),
     "mt_adam_multi": (_i, [_p, _p, _i, _i64, _f, _f, _f, _f, _f, _i, _p]),
+    "mt_adam_multi_dev": (_i, [_p, _p, _i, _i64, _f, _f, _f, _f, _p, _p]),
 }
 
 _lib = None

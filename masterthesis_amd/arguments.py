@@ -58,6 +58,9 @@ class Arguments:
         p.add_argument("--ckpt_module_prefix", action="store_true",
                        help="(new, optional) save model_*.ckpt with 'module.'-prefixed keys, as the reference's "
                             "DataParallel-wrapped GPU runs write and strictly expect them")
+        p.add_argument("--hip_graph", action="store_true",
+                       help="(new, optional) capture the training step into a hipGraph after 3 eager iterations and "
+                            "replay it (single process only): removes the per-launch host cost, e.g. at --batch_size 1")
         p.add_argument("--synthetic_len", type=int, default=64, help="items per epoch of SyntheticDataset")
 
     def _finish(self, args):

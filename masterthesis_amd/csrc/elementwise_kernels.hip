@@ -113,8 +113,10 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, fl
 }
 template <bool BF16>
 __global__ void noise_add_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, long nchunks,
-                                 unsigned long long seed, unsigned long long offset) {
+                                 unsigned long long seed, unsigned long long offset,
+                                 const unsigned long long* __restrict__ dev_state) {
   constexpr int V = Elem<BF16>::V;
+  if (dev_state) { seed = dev_state[0]; offset = dev_state[1] << 40; }    // {seed, draw counter} kept on the device
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
     float f[V];
     Elem<BF16>::unpack(x[i], f);
@@ -131,15 +133,35 @@ __global__ void noise_add_kernel(const u32x4* __restrict__ x, u32x4* __restrict_
     y[i] = Elem<BF16>::pack(f);
   }
 }
-extern "C" int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t seed, uint64_t offset,
-                                     mt_stream_t s) {
+static int launch_noise(int dtype, const void* x, void* y, size_t n, uint64_t seed, uint64_t offset,
+                        const uint64_t* dev_state, mt_stream_t s) {
   long nc;
   if (check_n(dtype, n, &nc)) return 1;
   if (nc == 0) return 0;
-  if (dtype == MT_BF16) hipLaunchKernelGGL((noise_add_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, (u32x4*)y, nc, seed, offset);
-  else hipLaunchKernelGGL((noise_add_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, (u32x4*)y, nc, seed, offset);
+  const unsigned long long* ds = (const unsigned long long*)dev_state;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((noise_add_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, (u32x4*)y, nc, seed, offset, ds);
+  else hipLaunchKernelGGL((noise_add_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x, (u32x4*)y, nc, seed, offset, ds);
   MT_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n, uint64_t seed, uint64_t offset,
+                                     mt_stream_t s) {
+  return launch_noise(dtype, x, y, n, seed, offset, nullptr, s);
+}
+// Device-resident generator state {seed, draw counter} (two uint64): the launch carries no host-side random value, so
+// it can be captured into a hipGraph and still draw fresh noise on every replay.  Draw k uses the Philox counter block
+// [k << 40, (k + 1) << 40); mt_rng_advance bumps the counter (stream ordered, after the draw).
+__global__ void rng_advance_kernel(unsigned long long* st) { st[1] += 1ull; }
+extern "C" int mt_rng_advance(uint64_t* dev_state, mt_stream_t s) {
+  MT_CHECK(dev_state != nullptr, "rng_advance: null state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (unsigned long long*)dev_state);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_gaussian_noise_add_dev(int dtype, const void* x, void* y, size_t n, const uint64_t* dev_state,
+                                         mt_stream_t s) {
+  MT_CHECK(dev_state != nullptr, "gaussian_noise_add_dev: null state");
+  return launch_noise(dtype, x, y, n, 0, 0, dev_state, s);
 }
 
 // ---- dropout (nn.Dropout(0.5) at the end of the decoders' residual branches, --use_dropout; blocks.py:133-134,153-165,
@@ -147,8 +169,10 @@ extern "C" int mt_gaussian_noise_add(int dtype, const void* x, void* y, size_t n
 // parity mode, else drawn here: Philox4x32-10, counter = element index), the same product serves the backward pass.
 template <bool BF16>
 __global__ void bernoulli_mask_kernel(u32x4* __restrict__ mask, long nchunks, int cchunks, int C, float keep,
-                                      unsigned long long seed, unsigned long long offset) {
+                                      unsigned long long seed, unsigned long long offset,
+                                      const unsigned long long* __restrict__ dev_state) {
   constexpr int V = Elem<BF16>::V;
+  if (dev_state) { seed = dev_state[0]; offset = dev_state[1] << 40; }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % cchunks) * V;
     float f[V];
@@ -163,16 +187,26 @@ __global__ void bernoulli_mask_kernel(u32x4* __restrict__ mask, long nchunks, in
     mask[i] = Elem<BF16>::pack(f);
   }
 }
-extern "C" int mt_bernoulli_mask(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed,
-                                 uint64_t offset, mt_stream_t s) {
+static int launch_bernoulli(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed, uint64_t offset,
+                            const uint64_t* dev_state, mt_stream_t s) {
   long nc;
   if (check_n(dtype, npix * (size_t)Cp, &nc)) return 1;
   if (nc == 0) return 0;
   const int cchunks = Cp / (dtype == MT_BF16 ? 8 : 4);
-  if (dtype == MT_BF16) hipLaunchKernelGGL((bernoulli_mask_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset);
-  else hipLaunchKernelGGL((bernoulli_mask_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset);
+  const unsigned long long* ds = (const unsigned long long*)dev_state;
+  if (dtype == MT_BF16) hipLaunchKernelGGL((bernoulli_mask_kernel<true>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset, ds);
+  else hipLaunchKernelGGL((bernoulli_mask_kernel<false>), dim3(EW_GRID(nc)), dim3(256), 0, (hipStream_t)s, (u32x4*)mask, nc, cchunks, C, keep, seed, offset, ds);
   MT_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int mt_bernoulli_mask(int dtype, void* mask, size_t npix, int C, int Cp, float keep, uint64_t seed,
+                                 uint64_t offset, mt_stream_t s) {
+  return launch_bernoulli(dtype, mask, npix, C, Cp, keep, seed, offset, nullptr, s);
+}
+extern "C" int mt_bernoulli_mask_dev(int dtype, void* mask, size_t npix, int C, int Cp, float keep,
+                                     const uint64_t* dev_state, mt_stream_t s) {
+  MT_CHECK(dev_state != nullptr, "bernoulli_mask_dev: null state");
+  return launch_bernoulli(dtype, mask, npix, C, Cp, keep, 0, 0, dev_state, s);
 }
 template <bool BF16>
 __global__ void mul_scale_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ y,

@@ -87,8 +87,11 @@ extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, fl
 // grid = (chunks, tensors).  torch.optim.Adam semantics (no amsgrad, maximize=False):
 //   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
 //   p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+struct AdamDevState { float lr; int step; float bc1; float bc2_sqrt; };   // mirror of the float[4] / int[4] buffer
 __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr,
-                                  float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                  float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                  const AdamDevState* __restrict__ dev) {
+  if (dev) { lr = dev->lr; bc1 = dev->bc1; bc2_sqrt = dev->bc2_sqrt; }
   const int t = blockIdx.y;
   float* __restrict__ p = (float*)ptrs[4 * t + 0];
   const float* __restrict__ g = (const float*)ptrs[4 * t + 1];
@@ -115,7 +118,28 @@ extern "C" int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count,
   int chunks = (int)((max_size + 256 * 8 - 1) / (256 * 8));
   if (chunks < 1) chunks = 1;
   if (chunks > 2048) chunks = 2048;
-  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, lr, beta1, beta2, eps, wd, bc1, bc2);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, lr, beta1, beta2, eps, wd, bc1, bc2, (const AdamDevState*)nullptr);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+// The same update with learning rate and step count read from a 16-byte device record {float lr; int32 step; float
+// 1 - beta1^step; float sqrt(1 - beta2^step)}: no host-side value changes from step to step, so the launch pair can be
+// captured into a hipGraph.  One tick (step += 1, bias corrections in double precision) precedes the update.
+__global__ void adam_tick_kernel(AdamDevState* st, float b1, float b2) {
+  const int t = st->step + 1;
+  st->step = t;
+  st->bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  st->bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+extern "C" int mt_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float beta1,
+                                 float beta2, float eps, float wd, void* dev_state, mt_stream_t s) {
+  if (count == 0) return 0;
+  MT_CHECK(dev_state != nullptr, "adam_multi_dev: null state");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (AdamDevState*)dev_state, beta1, beta2);
+  int chunks = (int)((max_size + 256 * 8 - 1) / (256 * 8));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 2048) chunks = 2048;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, 0.f, beta1, beta2, eps, wd, 1.f, 1.f, (const AdamDevState*)dev_state);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -70,6 +70,8 @@ class _ZeroArena:
     def __init__(self):
         self.buf = None
         self.off = self.dirty = self.need = self.asked = self.depth = 0
+        self.high = 0       # high-water mark of handed-out floats: the memset always covers it, so a step captured into a
+                            # hipGraph re-zeroes everything ANY kind of step may have dirtied before it
 
     def begin(self, device):
         self.depth += 1
@@ -78,6 +80,7 @@ class _ZeroArena:
         want = max(self.need, 1 << 18)
         if self.buf is None or self.buf.device != device or self.buf.numel() < want:
             self.buf = torch.zeros(int(want * 1.25), dtype=torch.float32, device=device)
+            self.high = 0
         elif self.dirty:
             self.buf[:self.dirty].zero_()
         self.off = self.dirty = self.asked = 0
@@ -86,7 +89,8 @@ class _ZeroArena:
         self.depth -= 1
         if self.depth == 0:
             self.need = max(self.need, self.asked)
-            self.dirty = self.off
+            self.high = max(self.high, self.off)
+            self.dirty = self.high
 
     def take(self, shape, device):
         n = 1
@@ -799,6 +803,41 @@ def gaussian_noise_add(x, seed, offset):
     if padc(x.shape[1]) != x.shape[1]:
         raise RuntimeError("gaussian_noise_add needs a channel count that is a multiple of 8")
     return _NoiseAdd.apply(x, int(seed), int(offset))
+
+
+class _NoiseAddDev(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, state):
+        x = canon(x)
+        y = new_act(*x.shape, x.dtype, x.device)
+        lib = L.load()
+        L.check(lib.mt_gaussian_noise_add_dev(_mt(x.dtype), _ptr(x), _ptr(y), _numel_padded(x), _ptr(state), _stream()),
+                "mt_gaussian_noise_add_dev")
+        L.check(lib.mt_rng_advance(_ptr(state), _stream()), "mt_rng_advance")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def gaussian_noise_add_dev(x, state):
+    """x + N(0,1) from the device-resident generator ``state`` (int64 [2] = {seed, draw counter}); the counter advances
+    in stream order, so the call is hipGraph-capturable and every replay draws fresh noise."""
+    if padc(x.shape[1]) != x.shape[1]:
+        raise RuntimeError("gaussian_noise_add needs a channel count that is a multiple of 8")
+    return _NoiseAddDev.apply(x, state)
+
+
+def bernoulli_mask_dev(shape, keep, state, device):
+    """0/1 mask ~ Bernoulli(keep) from the device-resident generator state (see gaussian_noise_add_dev)."""
+    N, Cc, H, W = shape
+    m = new_act(N, Cc, H, W, compute_dtype(), device)
+    lib = L.load()
+    L.check(lib.mt_bernoulli_mask_dev(_mt(m.dtype), _ptr(m), N * H * W, Cc, padc(Cc), float(keep), _ptr(state), _stream()),
+            "mt_bernoulli_mask_dev")
+    L.check(lib.mt_rng_advance(_ptr(state), _stream()), "mt_rng_advance")
+    return m
 
 
 class _Pool(torch.autograd.Function):

@@ -13,25 +13,36 @@ from ... import hip_ops as ops
 
 
 class DeviceRandom:
-    """Default source: noise generated on the GPU."""
+    """Default source: noise generated on the GPU.  The generator state {seed, draw counter} of the Philox kernels
+    lives in device memory: no random value is passed from the host per launch, so a whole training step can be
+    captured into a hipGraph and still draw fresh noise on every replay.  The seed is taken ONCE from torch's CPU
+    generator, so ``torch.manual_seed`` (and the per-rank reseeding of a multi-GPU run) still decide the stream."""
 
     def __init__(self):
-        self.offset = 0
+        self._state = {}
+
+    def state(self, device):
+        dev = torch.device(device)
+        if dev.index is None and dev.type == "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        st = self._state.get(dev)
+        if st is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            st = torch.tensor([seed, 0], dtype=torch.int64).to(dev)
+            self._state[dev] = st
+        return st
 
     def add_noise(self, x):
-        # seed from torch's CPU generator so torch.manual_seed() still makes runs reproducible
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        return ops.gaussian_noise_add(x, seed, 0)
+        return ops.gaussian_noise_add_dev(x, self.state(x.device))
 
     def eps(self, shape, device):
-        return torch.randn(shape, device=device)
+        return torch.randn(shape, device=device)        # (torch's device generator is hipGraph-safe as well)
 
     def z(self, shape, device):
         return torch.randn(shape, device=device)
 
     def dropout_mask(self, shape, device, keep=0.5):
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        return ops.bernoulli_mask(shape, keep, seed, 0, device)
+        return ops.bernoulli_mask_dev(shape, keep, self.state(device), device)
 
 
 class ReplaySource:

@@ -21,6 +21,9 @@ class FusedAdam(torch.optim.Adam):
                              "group (the reference builds one Adam per network, adain_model.py:57-71)")
         self._flat = None
         self._step_count_mt = 0
+        self.generation = 0          # bumped whenever the flat buffers are (re)built: captured graphs hold their addresses
+        self._dev = None             # 16-byte device record {float lr; int32 step; float bc1; float bc2_sqrt}
+        self._dev_lr = None
 
     # ---- flat storage ----
     def params(self):
@@ -58,6 +61,11 @@ class FusedAdam(torch.optim.Adam):
         self._flat = (fp, fg, fm, fv, total)
         self._ptrs = torch.tensor([fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr()], dtype=torch.int64).to(dev)
         self._sizes = torch.tensor([total], dtype=torch.int64).to(dev)
+        rec = torch.zeros(4, dtype=torch.float32)
+        rec.view(torch.int32)[1] = step
+        self._dev = rec.to(dev)
+        self._dev_lr = None
+        self.generation += 1
         ops.bump_epoch(ps)
 
     def flat_grad(self):
@@ -74,19 +82,36 @@ class FusedAdam(torch.optim.Adam):
     def zero_grad(self, set_to_none=False):
         self.flat_grad().zero_()
 
+    def sync_lr(self):
+        """Write the current learning rate into the device record if the scheduler changed it (one tiny fill; a no-op
+        on every other step).  A captured step graph calls this before each replay."""
+        if self._flat is None:
+            self._flatten()
+        lr = float(self.param_groups[0]["lr"])
+        if self._dev_lr != lr:
+            self._dev[0:1].fill_(lr)
+            self._dev_lr = lr
+
+    def advance_host_step(self, n):
+        """A replayed graph stepped this optimizer ``n`` times on the device: keep the host mirror (state_dict) in sync."""
+        self._step_count_mt += int(n)
+
     @torch.no_grad()
     def step(self, closure=None):
         if self._flat is None:
             self._flatten()
         g = self.param_groups[0]
+        self.sync_lr()
         self._step_count_mt += 1
         import ctypes as C
         from . import _lib as L
         b1, b2 = g["betas"]
-        L.check(L.load().mt_adam_multi(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
-                                       self._flat[4], float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                       float(g["weight_decay"]), self._step_count_mt,
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mt_adam_multi")
+        # learning rate, step count and bias corrections live in the device record (ticked by the call itself): no
+        # launch argument changes from step to step, so the update can be replayed from a captured hipGraph
+        L.check(L.load().mt_adam_multi_dev(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
+                                           self._flat[4], float(b1), float(b2), float(g["eps"]),
+                                           float(g["weight_decay"]), C.c_void_p(self._dev.data_ptr()), ops._stream()),
+                "mt_adam_multi_dev")
         ops.bump_epoch(self.params())
         ops.repack_params(self.params())    # all cached weight images of this network, one launch
 
