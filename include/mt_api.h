@@ -269,6 +269,22 @@ int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t ma
 int mt_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float beta1, float beta2,
                       float eps, float wd, void* dev_state, mt_stream_t s);
 
+/* ---- gradient exchange over RCCL / xGMI (C1): replaces nn.DataParallel, functions.py:98-101 ---------------- */
+/* One process per GPU.  Rank 0 creates a 128-byte id (mt_comm_unique_id) and hands it to the other ranks through any
+ * side channel (the host code broadcasts it over torch.distributed); every rank then calls mt_comm_init(.., device).
+ * mt_comm_allreduce_async: buf (fp32 [count], in place) <- AVERAGE over the ranks, enqueued on the communicator's own
+ * side stream behind everything `producer` has been given so far; returns a handle >= 0 (negative on error).
+ * mt_comm_wait: `consumer` waits on the device for that handle (no host blocking).  Up to 64 handles may be in flight.
+ * RCCL is dlopen()ed on first use: the library has no link-time dependency on it. */
+typedef struct mt_comm mt_comm;
+int mt_comm_unique_id(void* id128);
+int mt_comm_init(mt_comm** comm, int rank, int world, const void* id128, int device);
+int mt_comm_allreduce_async(mt_comm* comm, float* buf, size_t count, mt_stream_t producer);
+int mt_comm_wait(mt_comm* comm, int handle, mt_stream_t consumer);
+int mt_comm_rank(const mt_comm* comm);
+int mt_comm_world(const mt_comm* comm);
+int mt_comm_destroy(mt_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,11 +62,50 @@ def seed_rank_streams(base=None, group=None):
     return seed
 
 
+class NativeComm:
+    """The library's own RCCL communicator (``mt_comm_*`` in include/mt_api.h): rank 0 creates the 128-byte id, it
+    travels to the other ranks over the already initialised torch.distributed group, every rank joins with its device."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib as L
+        self.C, self.L, self.lib = C, L, L.load()
+        rank, world = rank_and_world(group)
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(self.lib.mt_comm_unique_id(idbuf), "mt_comm_unique_id")
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.frombuffer(idbuf, dtype=torch.uint8).clone().to(dev)
+        if world > 1:
+            dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        self.handle = C.c_void_p()
+        L.check(self.lib.mt_comm_init(C.byref(self.handle), rank, world, raw, torch.cuda.current_device()), "mt_comm_init")
+
+    def allreduce_async(self, buf, producer_stream):
+        h = self.lib.mt_comm_allreduce_async(self.handle, self.C.c_void_p(buf.data_ptr()), buf.numel(),
+                                             self.C.c_void_p(producer_stream))
+        if h < 0:
+            raise RuntimeError(f"mt_comm_allreduce_async failed: {self.lib.mt_last_error().decode(errors='replace')}")
+        return h
+
+    def wait(self, h, consumer_stream):
+        self.L.check(self.lib.mt_comm_wait(self.handle, h, self.C.c_void_p(consumer_stream)), "mt_comm_wait")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mt_comm_destroy(self.handle)
+            self.handle = None
+
+
 class GradReducer:
     """All-reduce (mean) of flat gradient buffers, asynchronously on a side stream when on GPU.
 
     ``reduce(buffers)`` enqueues one collective per buffer and returns handles; ``wait(handle)`` makes
-    the current stream wait for that buffer only.  Works with any backend (gloo on CPU for tests)."""
+    the current stream wait for that buffer only.  Works with any backend (gloo on CPU for tests).  On the GPU the
+    collective is issued either through torch.distributed (backend "nccl" = RCCL; the default) or, with
+    ``MT_COMM=native``, through the library's own RCCL communicator (``mt_comm_*``): same stream/event structure, one
+    ``ncclAllReduce(avg)`` per buffer, no separate scaling kernel."""
 
     def __init__(self, group=None):
         # MT_FORCE_REDUCER=1 keeps the exchange path active at world_size 1 (exercises RCCL + the side stream
@@ -76,12 +115,21 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.side = None
+        self.native = None
+        self.log = None                 # tests: list that receives ("reduce" | "wait", ...) records
+        if self.enabled and torch.cuda.is_available() and os.environ.get("MT_COMM", "torch") == "native":
+            self.native = NativeComm(group)
 
     def reduce(self, buffers):
         handles = []
         if not self.enabled:
             return [None for _ in buffers]
         on_gpu = buffers and buffers[0].is_cuda
+        if self.log is not None:
+            self.log.append(("reduce", [int(b.numel()) for b in buffers]))
+        if on_gpu and self.native is not None:
+            cur = torch.cuda.current_stream().cuda_stream
+            return [("native", self.native.allreduce_async(b, cur)) for b in buffers]
         if on_gpu:
             if self.side is None:
                 self.side = torch.cuda.Stream()
@@ -102,11 +150,14 @@ class GradReducer:
                 handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return handles
 
-    @staticmethod
-    def wait(handle):
+    def wait(self, handle):
         if handle is None:
             return
-        if isinstance(handle, torch.cuda.Event):
+        if self.log is not None:
+            self.log.append(("wait",))
+        if isinstance(handle, tuple) and handle[0] == "native":
+            self.native.wait(handle[1], torch.cuda.current_stream().cuda_stream)
+        elif isinstance(handle, torch.cuda.Event):
             torch.cuda.current_stream().wait_event(handle)
         else:
             handle.wait()

@@ -407,6 +407,12 @@ class _Conv(torch.autograd.Function):
         ctx.desc = desc
         ctx.owner = owner
         ctx.bias_owner = bias
+        # uses of this weight whose weight gradient is still to come in the backward pass under construction: when the
+        # count returns to zero the parameter's gradient is final (it is accumulated straight into param.grad), which
+        # is what lets the data-parallel exchange of a bucket start INSIDE the backward pass (set_grad_ready_hook)
+        ctx.counted = bool(owner.requires_grad and owner.is_leaf and torch.is_grad_enabled())
+        if ctx.counted:
+            owner._mt_pending = getattr(owner, "_mt_pending", 0) + 1
         # the statistics output never carries a gradient: without this autograd materialises a zero tensor for it
         # on every backward call (57 fill kernels per step)
         ctx.set_materialize_grads(False)
@@ -424,6 +430,7 @@ class _Conv(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         desc = ctx.desc
         if dy is None:
+            _grad_use_done(ctx)
             return None, None, None, None
         dy = canon(dy)
         if desc.act != L.ACT_NONE:
@@ -460,7 +467,25 @@ class _Conv(torch.autograd.Function):
                 with _oplog("wgrad", desc, (int(want_b),)):
                     L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
                                                    0, _stream()), "mt_conv_bwd_weight")
+        _grad_use_done(ctx)
         return dx, dw, db, None
+
+
+def _grad_use_done(ctx):
+    if not ctx.counted:
+        return
+    owner = ctx.owner
+    owner._mt_pending = getattr(owner, "_mt_pending", 1) - 1
+    if owner._mt_pending == 0:
+        hook = getattr(owner, "_mt_ready_hook", None)
+        if hook is not None:
+            hook(owner)
+
+
+def set_grad_ready_hook(param, fn):
+    """``fn(param)`` is called from the backward pass right after the LAST weight-gradient launch of ``param`` in the
+    current graph has been enqueued (None clears it).  Only meaningful with fused gradient accumulation."""
+    param._mt_ready_hook = fn
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01, stats=False, bias_grad=True):

@@ -190,6 +190,7 @@ class TranslationModel(Model):
         return torch.split(fake, B, dim=0)
 
     def _reduce_and_step(self, names):
+        self._mark("exchange " + "+".join(names))
         opts = [self.optimizer[n] for n in names]
         handles = self.reducer.reduce([o.flat_grad() for o in opts])
         for o, h in zip(opts, handles):
@@ -269,14 +270,17 @@ class TranslationModel(Model):
         # the gradient exchange of discriminator1 (side stream) overlaps discriminator2's forward + backward
         pending = []
         for name, fake in (("discriminator1", img_fake), ("discriminator2", img_random)):
-            self.optimizer[name].zero_grad()
-            self.backward_discriminator(self.model[name], img, fake, c_org)
+            self._mark(name)
             opt = self.optimizer[name]
-            pending.append((opt, self.reducer.reduce([opt.flat_grad()])[0]))
+            opt.zero_grad()
+            early = self._arm_early_exchange(opt)
+            self.backward_discriminator(self.model[name], img, fake, c_org)
+            pending.append((opt, self._finish_early_exchange(opt, early)))
         # discriminator1 is needed by phase 3; discriminator2 only by phase 4, so with a live exchange its wait + Adam
         # step move in front of phase 4 and its all-reduce also hides behind the whole of phase 3
         (opt1, h1), d2 = pending
-        self.reducer.wait(h1)
+        for h in h1:
+            self.reducer.wait(h)
         opt1.step()
         if self.reducer.enabled:
             self._deferred_steps = [d2]
@@ -285,9 +289,54 @@ class TranslationModel(Model):
 
     def _finish_deferred(self, items=None):
         items = self.__dict__.pop("_deferred_steps", []) if items is None else items
-        for opt, h in items:
-            self.reducer.wait(h)
+        for opt, handles in items:
+            for h in handles:
+                self.reducer.wait(h)
             opt.step()
+
+    def _mark(self, what):
+        if self.reducer.log is not None:
+            self.reducer.log.append(("phase", what))
+
+    # ---- exchange that starts inside the backward pass (discriminator phases) -----------------------------
+    def _arm_early_exchange(self, opt):
+        """Bucketed all-reduce launched from the backward pass itself: as soon as the last weight-gradient kernel of a
+        bucket has been enqueued (hip_ops.set_grad_ready_hook), its slice of the flat gradient buffer goes to the side
+        stream -- for a discriminator the 9.4 M-parameter last convolution is produced FIRST, so most of the exchange
+        runs under the rest of the backward pass.  Needs every parameter's gradient to be accumulated by our own
+        backward kernels (plain convolution stacks: not with spectral norm or BatchNorm holders)."""
+        a = self.args
+        if not self.reducer.enabled or getattr(a, "dis_sn", False) or getattr(a, "dis_norm", None) is not None \
+                or os.environ.get("MT_NO_EARLY_EXCHANGE", "0") == "1":
+            return None
+        state = {"handles": [], "buckets": []}
+        flat = opt.flat_grad()
+        for lo, hi, members in opt.grad_buckets():
+            b = {"lo": lo, "hi": hi, "left": len(members), "sent": False}
+            state["buckets"].append(b)
+
+            def ready(_p, b=b):
+                b["left"] -= 1
+                if b["left"] == 0 and not b["sent"]:
+                    b["sent"] = True
+                    state["handles"] += self.reducer.reduce([flat[b["lo"]:b["hi"]]])
+            for p in members:
+                ops.set_grad_ready_hook(p, ready)
+            state.setdefault("params", []).extend(members)
+        return state
+
+    def _finish_early_exchange(self, opt, state):
+        """-> the handles the optimizer step has to wait for"""
+        if state is None:
+            return self.reducer.reduce([opt.flat_grad()])
+        for p in state.get("params", []):
+            ops.set_grad_ready_hook(p, None)
+        flat = opt.flat_grad()
+        for b in state["buckets"]:              # (a bucket none of whose weights was used in this graph)
+            if not b["sent"]:
+                b["sent"] = True
+                state["handles"] += self.reducer.reduce([flat[b["lo"]:b["hi"]]])
+        return state["handles"]
 
     def _dis_outputs(self, netD, x):
         out = netD(x)

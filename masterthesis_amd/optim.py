@@ -58,6 +58,7 @@ class FusedAdam(torch.optim.Adam):
             self.state[p] = {"step": torch.tensor(float(step)), "exp_avg": fm[o:o + n].view(p.shape),
                              "exp_avg_sq": fv[o:o + n].view(p.shape)}
         self._step_count_mt = step
+        self._offsets = offs
         self._flat = (fp, fg, fm, fv, total)
         self._ptrs = torch.tensor([fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr()], dtype=torch.int64).to(dev)
         self._sizes = torch.tensor([total], dtype=torch.int64).to(dev)
@@ -81,6 +82,37 @@ class FusedAdam(torch.optim.Adam):
     # ---- torch.optim API ----
     def zero_grad(self, set_to_none=False):
         self.flat_grad().zero_()
+        for p in self.params():
+            p._mt_pending = 0           # (see hip_ops._Conv: uses whose weight gradient is still to come)
+
+    def grad_buckets(self, nbuckets=2, min_elems=None):
+        """Split the flat gradient buffer at parameter boundaries into up to ``nbuckets`` contiguous ranges, LAST
+        parameters first: a backward pass produces gradients in reverse parameter order, so bucket 0 (the tail of the
+        buffer -- for the discriminators their 9.4 M-parameter last convolution) is complete almost as soon as the
+        backward pass starts.  -> list of (start, end, [weight parameters whose readiness completes the bucket])."""
+        if self._flat is None:
+            self._flatten()
+        if min_elems is None:           # (a collective below ~4 MB is latency bound: do not split small networks)
+            import os
+            min_elems = int(os.environ.get("MT_BUCKET_MIN_ELEMS", str(1 << 20)))
+        ps, offs = self.params(), self._offsets
+        total = self._flat[4]
+        bounds = [total]
+        want = max(total // max(int(nbuckets), 1), int(min_elems))
+        acc = 0
+        for i in range(len(ps) - 1, 0, -1):
+            acc += offs[i + 1] - offs[i] if i + 1 < len(ps) else total - offs[i]
+            # cut in front of a weight (dim > 1) so a bias stays with its weight
+            if acc >= want and ps[i].dim() > 1 and len(bounds) < nbuckets:
+                bounds.append(offs[i])
+                acc = 0
+        bounds.append(0)
+        out = []
+        for hi, lo in zip(bounds[:-1], bounds[1:]):
+            if hi > lo:
+                members = [p for p, o in zip(ps, offs) if lo <= o < hi and p.dim() > 1]
+                out.append((lo, hi, members))
+        return out
 
     def sync_lr(self):
         """Write the current learning rate into the device record if the scheduler changed it (one tiny fill; a no-op

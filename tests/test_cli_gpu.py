@@ -119,9 +119,15 @@ def test_inference_surface(precision, tmp_path, hip_device):
     assert secs >= 0 and gib >= 0
 
 
-def test_rccl_exchange_path_single_rank(tmp_path, hip_device, monkeypatch):
+@pytest.mark.parametrize("comm", ["torch", "native"])
+def test_rccl_exchange_path_single_rank(comm, tmp_path, hip_device, monkeypatch):
     """World-size-1 RCCL process group with the gradient exchange forced on: the side-stream all-reduce,
-    event waits and per-network Adam ordering run for real; losses must equal a run without the exchange."""
+    event waits and per-network Adam ordering run for real; losses must equal a run without the exchange.
+    comm = "native": the collective goes through the library's own communicator (mt_comm_* over RCCL).
+    Also pins WHERE the exchanges are enqueued: the two buckets of a discriminator from inside its backward pass
+    (the 9.4 M-parameter tail first), everything of a phase before the next phase's first launch."""
+    monkeypatch.setenv("MT_COMM", comm)
+    monkeypatch.setenv("MT_BUCKET_MIN_ELEMS", "1024")       # (the fixture's discriminators are tiny)
     import socket
     import torch.distributed as dist
     from helpers import load_gold, product_args, sub
@@ -133,7 +139,9 @@ def test_rccl_exchange_path_single_rank(tmp_path, hip_device, monkeypatch):
         z, meta = load_gold("adain_step_d2")
         M = models.AdaINModel(product_args(meta["args"], str(tmp_path), "fp32"))
         assert M.reducer.enabled == force
+        assert (M.reducer.native is not None) == (force and comm == "native")
         M.initialize()
+        log = M.reducer.log = [] if force else None
         for net in M.model:
             M.model[net].load_state_dict(sub(z, f"init/{net}"))
         out = []
@@ -144,6 +152,28 @@ def test_rccl_exchange_path_single_rank(tmp_path, hip_device, monkeypatch):
             M.optimize_parameters(it)
             out.append(dict(M.sync_losses()))
         misc.set_random_source(None)
+        if force:
+            n_d = sum(p.numel() + (-p.numel() % 4) for p in M.model.discriminator1.parameters())
+            per_step = len(log) // 2
+            for it in range(2):
+                ev = log[it * per_step:(it + 1) * per_step]
+                kinds = [e[0] if e[0] != "phase" else e[1] for e in ev]
+                # discriminator phases: two bucket exchanges each, issued before the next phase is entered
+                i1, i2 = kinds.index("discriminator1"), kinds.index("discriminator2")
+                i3 = kinds.index("exchange content_encoder+style_encoder+decoder")
+                r1 = [e[1] for e in ev[i1:i2] if e[0] == "reduce"]
+                r2 = [e[1] for e in ev[i2:i3] if e[0] == "reduce"]
+                assert len(r1) == 2 and len(r2) == 2, (r1, r2)
+                assert sum(x[0] for x in r1) == n_d and r1[0][0] > r1[1][0], r1        # the big tail bucket goes first
+                # discriminator1 is stepped (1 wait per bucket) before phase 3; discriminator2's waits come after the
+                # phase-3 exchange was enqueued (its step is deferred to the start of phase 4)
+                assert kinds[i2:i3].count("wait") == 2
+                i4 = kinds.index("exchange content_encoder+decoder")
+                assert [e[1] for e in ev[i3:i4] if e[0] == "reduce"] == [[M.optimizer[n].flat_grad().numel() for n in
+                                                                         ("content_encoder", "style_encoder", "decoder")]]
+                assert kinds[i3:i4].count("wait") == 3 + 2
+        if M.reducer.native is not None:
+            M.reducer.native.close()
         return out
 
     s = socket.socket()

@@ -194,3 +194,61 @@ def test_product_model_two_ranks_same_weights_different_streams(tmp_path):
     assert seed1 == seed0 + 1 and d0 != d1, "ranks draw from the same random stream"
     assert x0 != x1, "ranks read the same samples"
     assert n0 == n1 == 8 // 2 // 1                      # 8 items, 2 ranks, batch_size 1
+
+
+class _FakeOpt:
+    def __init__(self, name, buf, trace):
+        self.name, self.buf, self.trace = name, buf, trace
+
+    def flat_grad(self):
+        return self.buf
+
+    def step(self):
+        self.trace.append(("step", self.name, self.buf.clone()))
+
+
+def _worker_phase_order(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from types import SimpleNamespace
+    from masterthesis_amd.distributed import GradReducer, init_from_env
+    from masterthesis_amd.models.translation import TranslationModel
+    init_from_env(backend="gloo")
+    red = GradReducer()
+    red.log = []
+    trace = []
+    names = ("content_encoder", "style_encoder", "decoder")
+    # recorded flat gradients: rank r holds (r + 1) * base
+    base = {n: torch.arange(1, 6, dtype=torch.float32) * (i + 1) for i, n in enumerate(names)}
+    fake = SimpleNamespace(reducer=red, optimizer={n: _FakeOpt(n, base[n] * (rank + 1), trace) for n in names})
+    fake._mark = lambda what: TranslationModel._mark(fake, what)
+    TranslationModel._reduce_and_step(fake, names)
+    # a deferred discriminator step (update_discriminator leaves it for the start of phase 4)
+    d2 = _FakeOpt("discriminator2", torch.full((4,), float(rank + 1)), trace)
+    fake._deferred_steps = [(d2, red.reduce([d2.flat_grad()]))]
+    fake.__dict__["_deferred_steps"] = fake._deferred_steps
+    TranslationModel._finish_deferred(fake)
+    q.put((rank, [(k, n, b.tolist()) for k, n, b in trace], [e[0] for e in red.log]))
+    dist.destroy_process_group()
+
+
+def test_phase_exchange_and_step_order_two_ranks():
+    """The product's ``_reduce_and_step`` / ``_finish_deferred`` on two gloo ranks with recorded flat gradient buffers:
+    ALL buffers of a phase are handed to the exchange before the first optimizer steps, every optimizer steps on the
+    rank average of ITS buffer, a deferred step waits for its own handle (reference hook replaced: functions.py:98-101)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_phase_order, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, trace, log in out:
+        assert [n for _, n, _ in trace] == ["content_encoder", "style_encoder", "decoder", "discriminator2"]
+        for i, (_, n, buf) in enumerate(trace[:3]):
+            assert buf == pytest.approx([v * (i + 1) * 1.5 for v in range(1, 6)]), (rank, n, buf)     # mean of 1x and 2x
+        assert trace[3][2] == pytest.approx([1.5] * 4)
+        assert log[:2] == ["phase", "reduce"] and log.count("wait") == 4
