@@ -555,13 +555,19 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   if (mt_pointwise_small(d)) {
     // streaming outer-product reduction into fp32 [Cop][Cip], then the generic unpack (rows = co)
     if (dw != nullptr) {
-      if (hipMemsetAsync(ws, 0, (size_t)Cop * Cip * sizeof(float), s) != hipSuccess) { mt_set_error("memset"); return 2; }
-      if (mt_pw_bwd_weight(d, x, dy, (float*)ws, (long)d->N * d->H * d->W, s)) return 2;
+      // one fp32 slab [Cop][Cip] per block (no atomics, nothing to zero); the unpack adds the slabs in index order
+      const long slab = (long)Cop * Cip;
+      int nslabs = 0;
+      const int max_slabs = (int)min((size_t)1024, ws_bytes / (slab * sizeof(float)));
+      if (mt_pw_bwd_weight(d, x, dy, (float*)ws, (long)d->N * d->H * d->W, max_slabs, &nslabs, s)) {
+        mt_set_error("conv_bwd_weight: thin 1x1 weight gradient could not be launched");
+        return 2;
+      }
       PackParams u;
       memset(&u, 0, sizeof(u));
       u.kW = 1; u.ntaps = 1; u.R = d->Co; u.C = d->Ci; u.Cp = Cip;
       if (d->transposed) { u.sr = 1; u.sc = d->Co; } else { u.sr = d->Ci; u.sc = 1; }
-      if (mt_launch_unpack((const float*)ws, dw, u, 1, (long)Cop * Cip, accumulate, s)) return 2;
+      if (mt_launch_unpack((const float*)ws, dw, u, nslabs, slab, accumulate, s)) return 2;
     }
     if (dbias != nullptr) {
       if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;

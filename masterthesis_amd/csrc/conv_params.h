@@ -117,4 +117,5 @@ struct mt_conv_desc;
 bool mt_pointwise_small(const mt_conv_desc* d);
 int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const float* bias, void* y, long npix, hipStream_t s);
 int mt_pw_bwd_data(const mt_conv_desc* d, const void* dy, const void* wpack, void* dx, long npix, hipStream_t s);
-int mt_pw_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* out, long npix, hipStream_t s);
+int mt_pw_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* out, long npix, int max_slabs,
+                     int* nslabs, hipStream_t s);

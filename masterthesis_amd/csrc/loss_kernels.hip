@@ -1,5 +1,5 @@
-// Scalar loss reductions and their gradients (fp32 accumulation, wavefront-shuffle reduce,
-// one fp32 atomic per wave into the zeroed scalar).
+// Scalar loss reductions and their gradients (fp32 accumulation, wavefront-shuffle reduce, block partials combined
+// by the last block to finish in block-index order: reproducible, no floating-point atomics).
 // Reference: GANLoss vanilla = BCEWithLogitsLoss vs constant 0/1 (loss.py:52-64),
 // classification BCEWithLogitsLoss vs one-hot (adain_model.py:74), L1Loss (303-305,379-380),
 // _l2_regularize (396-399), reparameterize (networks.py:130-135), KL sum (adain_model.py:313-314).
@@ -7,9 +7,42 @@
 
 #define RED_GRID(total) (int)min((long)1024, ((long)(total) + 255) / 256)
 
-__device__ __forceinline__ void wave_atomic_add(float* dst, float v) {
+// Grid-wide sum of one value per thread into *dst, bit-reproducible: wave shuffle, the block's waves in index order,
+// the block partial into a scratch slot; the block that takes the last ticket adds the slots in a fixed order and
+// writes the scalar.  The scratch is a module-level device array: launches that use it must be stream ordered with
+// respect to each other (the library's loss kernels all run on the caller's one compute stream).  grid <= 1024 blocks
+// of 256 threads; EVERY thread of every block must call it exactly once.
+__device__ float g_red_part[1024];
+__device__ unsigned g_red_ticket = 0;
+__device__ __forceinline__ void grid_sum_to(float* dst, float v) {
+  __shared__ float sw[4];
+  __shared__ int last;
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sw[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+    __hip_atomic_store(&g_red_part[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned t = atomicAdd(&g_red_ticket, 1u);
+    last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    float a = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+      a += __hip_atomic_load(&g_red_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = wave_sum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sw[w] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *dst = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+      g_red_ticket = 0;
+    }
+  }
 }
 // numerically stable BCE-with-logits: max(x,0) - x*t + log(1+exp(-|x|))
 __device__ __forceinline__ float bce_logits(float x, float t) {
@@ -36,7 +69,7 @@ __global__ void bce_const_fwd_kernel(const void* __restrict__ x, float t, float*
     else v = reinterpret_cast<const float*>(x)[px * Cp + c];
     a += bce_logits(v, t);
   }
-  wave_atomic_add(loss, a * inv_count);
+  grid_sum_to(loss, a * inv_count);
 }
 template <bool BF16>
 __global__ void bce_const_bwd_kernel(const void* __restrict__ x, float t, const float* __restrict__ gscale,
@@ -111,7 +144,7 @@ __global__ void gan_const_fwd_kernel(int mode, const void* __restrict__ x, float
     else v = reinterpret_cast<const float*>(x)[px * Cp + c];
     a += gan_term(mode, v, t);
   }
-  wave_atomic_add(loss, a * inv_count);
+  grid_sum_to(loss, a * inv_count);
 }
 template <bool BF16>
 __global__ void gan_const_bwd_kernel(int mode, const void* __restrict__ x, float t, const float* __restrict__ gscale,
@@ -163,7 +196,7 @@ __global__ void bce_target_fwd_kernel(const float* __restrict__ x, const float* 
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     a += bce_logits(x[i], t[i]);
-  wave_atomic_add(loss, a * inv);
+  grid_sum_to(loss, a * inv);
 }
 __global__ void bce_target_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                       const float* __restrict__ gscale, float* __restrict__ dx, long n,
@@ -206,7 +239,7 @@ __global__ void absdiff_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __r
       for (int e = 0; e < V; e++) acc += f[e] * f[e];
     }
   }
-  wave_atomic_add(loss, acc * inv);
+  grid_sum_to(loss, acc * inv);
 }
 template <bool BF16, int MODE>
 __global__ void absdiff_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
@@ -308,7 +341,7 @@ __global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restr
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     a += 1.f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
-  wave_atomic_add(kl, -0.5f * a);
+  grid_sum_to(kl, -0.5f * a);
 }
 __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                               const float* __restrict__ gscale, float* __restrict__ dmu,

@@ -96,15 +96,14 @@ __global__ __launch_bounds__(256) void pw_bwd_data_kernel(const u32x4* __restric
   }
 }
 
-// out[co][ci] += sum_px dy[px][co] x[px][ci]   (fp32, caller zeroes `out`)
+// slab[block][co][ci] = sum over the block's pixels of dy[px][co] x[px][ci]   (fp32; every block writes its whole
+// slab, the caller adds the slabs in index order -- mt_launch_unpack -- so the result is reproducible: no atomics)
 template <bool BF16, int COP, int LP>
 __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
                                                             float* __restrict__ out, long npix) {
   constexpr int V = Elem<BF16>::V;
   constexpr int Cip = LP * V;
-  __shared__ float sacc[COP * Cip];
-  for (int i = threadIdx.x; i < COP * Cip; i += blockDim.x) sacc[i] = 0.f;
-  __syncthreads();
+  __shared__ float sacc[4][COP * Cip];
   const int chunk = threadIdx.x % LP;
   const long ngroups = npix * LP;
   float acc[COP][V];
@@ -123,12 +122,20 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const u32x4* __restr
 #pragma unroll
       for (int e = 0; e < V; e++) acc[co][e] += gy[co] * xf[e];
   }
+  // lanes of a wave that own the same channel chunk (lane % LP), then the four waves in index order
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int co = 0; co < COP; co++)
 #pragma unroll
-    for (int e = 0; e < V; e++) atomicAdd(&sacc[co * Cip + chunk * V + e], acc[co][e]);
+    for (int e = 0; e < V; e++) {
+      float v = acc[co][e];
+#pragma unroll
+      for (int o = LP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LP) sacc[wv][co * Cip + chunk * V + e] = v;
+    }
   __syncthreads();
-  for (int i = threadIdx.x; i < COP * Cip; i += blockDim.x) atomicAdd(out + i, sacc[i]);
+  float* slab = out + (long)blockIdx.x * (COP * Cip);
+  for (int i = threadIdx.x; i < COP * Cip; i += blockDim.x) slab[i] = (sacc[0][i] + sacc[1][i]) + (sacc[2][i] + sacc[3][i]);
 }
 
 bool mt_pointwise_small(const mt_conv_desc* d) {
@@ -185,9 +192,14 @@ int mt_pw_bwd_data(const mt_conv_desc* d, const void* dy, const void* wpack, voi
   MT_LAUNCH_CHECK();
   return 0;
 }
-int mt_pw_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* out, long npix, hipStream_t s) {
+// `out` receives `*nslabs` slabs of [Cop][Cip] floats (at most max_slabs), one per block
+int mt_pw_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* out, long npix, int max_slabs,
+                     int* nslabs, hipStream_t s) {
   const long groups = npix * (mt_padc(d->Ci) / (d->dtype == MT_BF16 ? 8 : 4));
-  const int grid = (int)min((long)1024, (groups + 255) / 256);
+  int grid = (int)min((long)1024, (groups + 255) / 256);
+  if (grid > max_slabs) grid = max_slabs;
+  if (grid < 1) return -1;
+  *nslabs = grid;
   PW_DISPATCH(pw_bwd_weight_kernel, (const u32x4*)x, (const u32x4*)dy, out, npix);
   MT_LAUNCH_CHECK();
   return 0;

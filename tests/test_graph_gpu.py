@@ -115,3 +115,23 @@ def test_graph_mode_is_refused_for_host_injected_draws(tmp_path, hip_device):
     finally:
         misc.set_random_source(None)
     assert M._graph_mode()
+
+
+def test_deterministic_mode_is_bit_reproducible(tmp_path, hip_device):
+    """MT_DETERMINISTIC / hip_ops.set_deterministic(True): every reduction runs in a fixed order (two-stage statistics,
+    ticketed loss reductions, slab sums; the atomics of the fused convolution-statistics epilogue are switched off), so
+    two runs from the same seed give BIT-identical losses and parameters over 10 steps -- in bf16 as well."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_deterministic(True)
+    try:
+        runs = []
+        for r in range(2):
+            M, hist = _run(str(tmp_path / str(r)), False, 10, hip_device, precision="bf16" if r < 2 else "fp32")
+            flat = torch.cat([p.detach().flatten() for net in M.model for p in M.model[net].parameters()]).clone()
+            runs.append((hist, flat))
+        (h0, p0), (h1, p1) = runs
+        for it, (a, b) in enumerate(zip(h0, h1)):
+            assert a == b, f"iteration {it}: losses differ between two identical-seed runs: {a} vs {b}"
+        assert torch.equal(p0, p1), "parameters differ between two identical-seed deterministic runs"
+    finally:
+        ops.set_deterministic(False)
