@@ -257,6 +257,16 @@ int mt_kl_fwd(const float* mu, const float* logvar, float* kl, size_t n, mt_stre
 int mt_kl_bwd(const float* mu, const float* logvar, const float* gscale, float* dmu,
               float* dlogvar, size_t n, mt_stream_t s);
 
+/* The model's loss expression in one launch (adain_model.py:193-195, 316-321, 381-389).  terms: HOST array of n device
+ * scalars; term i has weight w[i] and belongs to group gid[i] < G.  out (device, G + 2 floats): out[g] = sum of the
+ * weighted terms of group g (the values the model logs), out[G] = sum_g Wb[g]*out[g] (the loss that is differentiated),
+ * out[G+1] = sum_g Wr[g]*out[g] (the reported total; Wr NULL = Wb).  n <= 16, G <= 8; fixed summation order.
+ * mt_loss_sum_bwd: dterms[i] = gtotal * Wb[gid[i]] * w[i]. */
+int mt_loss_sum_fwd(const float* const* terms, const float* w, const int* gid, int n, const float* Wb, const float* Wr,
+                    int G, float* out, mt_stream_t s);
+int mt_loss_sum_bwd(const float* gtotal, const float* w, const int* gid, int n, const float* Wb, int G, float* dterms,
+                    mt_stream_t s);
+
 /* ---- optimizer (K20): torch.optim.Adam, adain_model.py:57-61 -------------------------- */
 /* One fused launch over `count` tensors.  ptrs: device array of 4*count pointers laid out
  * [p0,g0,m0,v0,p1,...]; sizes: device array of element counts; L2-coupled weight decay. */
@@ -265,9 +275,10 @@ int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t ma
 /* The same update with the per-step scalars on the device: dev_state = 16 bytes {float lr; int32 step; float bc1; float
  * bc2_sqrt}.  The call first ticks the record (step += 1, bias corrections recomputed in double precision), then updates
  * with it -- no launch argument changes between steps, so the pair is hipGraph-capturable.  The caller initialises
- * lr and step (bc* are outputs) and rewrites lr when the schedule changes it. */
+ * lr and step (bc* are outputs) and rewrites lr when the schedule changes it.  zero_grads != 0: the gradient buffers
+ * are cleared in the same pass (they were just read), which replaces the separate zero_grad() memset. */
 int mt_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float beta1, float beta2,
-                      float eps, float wd, void* dev_state, mt_stream_t s);
+                      float eps, float wd, void* dev_state, int zero_grads, mt_stream_t s);
 
 /* ---- gradient exchange over RCCL / xGMI (C1): replaces nn.DataParallel, functions.py:98-101 ---------------- */
 /* One process per GPU.  Rank 0 creates a 128-byte id (mt_comm_unique_id) and hands it to the other ranks through any

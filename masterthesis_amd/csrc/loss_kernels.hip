@@ -367,3 +367,58 @@ extern "C" int mt_kl_bwd(const float* mu, const float* logvar, const float* gsca
   MT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- weighted sum of loss scalars: the whole "loss = a + 10*b + 0.01*c ..." expression in ONE launch -------------------
+// (adain_model.py:193-195, 316-321, 381-389).  Term i (device scalar) belongs to group gid[i] with weight w[i]:
+//   out[g] = sum_{i in g} w[i]*t[i]  (g < G: the values the model logs),  out[G] = sum_g Wb[g]*out[g]  (what is
+//   differentiated),  out[G+1] = sum_g Wr[g]*out[g]  (what is reported as the total).
+#define MT_LOSS_MAX_TERMS 16
+#define MT_LOSS_MAX_GROUPS 8
+struct LossSumArgs {
+  const float* t[MT_LOSS_MAX_TERMS];
+  float w[MT_LOSS_MAX_TERMS];
+  int gid[MT_LOSS_MAX_TERMS];
+  float Wb[MT_LOSS_MAX_GROUPS], Wr[MT_LOSS_MAX_GROUPS];
+  int n, G;
+};
+__global__ void loss_sum_fwd_kernel(LossSumArgs a, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float v[MT_LOSS_MAX_GROUPS];
+  for (int g = 0; g < a.G; g++) v[g] = 0.f;
+  for (int i = 0; i < a.n; i++) v[a.gid[i]] += a.w[i] * a.t[i][0];      // fixed order
+  float tb = 0.f, tr = 0.f;
+  for (int g = 0; g < a.G; g++) { out[g] = v[g]; tb += a.Wb[g] * v[g]; tr += a.Wr[g] * v[g]; }
+  out[a.G] = tb;
+  out[a.G + 1] = tr;
+}
+__global__ void loss_sum_bwd_kernel(LossSumArgs a, const float* __restrict__ g, float* __restrict__ dt) {
+  const int i = threadIdx.x;
+  if (i < a.n) dt[i] = g[0] * a.Wb[a.gid[i]] * a.w[i];
+}
+static int fill_loss_args(LossSumArgs* a, const float* const* terms, const float* w, const int* gid, int n,
+                          const float* Wb, const float* Wr, int G) {
+  MT_CHECK(n >= 1 && n <= MT_LOSS_MAX_TERMS && G >= 1 && G <= MT_LOSS_MAX_GROUPS, "loss_sum: %d terms, %d groups", n, G);
+  a->n = n; a->G = G;
+  for (int i = 0; i < n; i++) {
+    MT_CHECK(gid[i] >= 0 && gid[i] < G && (terms == nullptr || terms[i] != nullptr), "loss_sum: bad term %d", i);
+    a->t[i] = terms ? terms[i] : nullptr; a->w[i] = w[i]; a->gid[i] = gid[i];
+  }
+  for (int g = 0; g < G; g++) { a->Wb[g] = Wb[g]; a->Wr[g] = Wr ? Wr[g] : Wb[g]; }
+  return 0;
+}
+extern "C" int mt_loss_sum_fwd(const float* const* terms, const float* w, const int* gid, int n, const float* Wb,
+                               const float* Wr, int G, float* out, mt_stream_t s) {
+  LossSumArgs a;
+  if (fill_loss_args(&a, terms, w, gid, n, Wb, Wr, G)) return 1;
+  hipLaunchKernelGGL(loss_sum_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a, out);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_loss_sum_bwd(const float* gtotal, const float* w, const int* gid, int n, const float* Wb, int G,
+                               float* dterms, mt_stream_t s) {
+  LossSumArgs a;
+  if (fill_loss_args(&a, nullptr, w, gid, n, Wb, nullptr, G)) return 1;
+  hipLaunchKernelGGL(loss_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a, gtotal, dterms);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -90,11 +90,11 @@ extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, fl
 struct AdamDevState { float lr; int step; float bc1; float bc2_sqrt; };   // mirror of the float[4] / int[4] buffer
 __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr,
                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                  const AdamDevState* __restrict__ dev) {
+                                  const AdamDevState* __restrict__ dev, int zero_grads) {
   if (dev) { lr = dev->lr; bc1 = dev->bc1; bc2_sqrt = dev->bc2_sqrt; }
   const int t = blockIdx.y;
   float* __restrict__ p = (float*)ptrs[4 * t + 0];
-  const float* __restrict__ g = (const float*)ptrs[4 * t + 1];
+  float* __restrict__ g = (float*)ptrs[4 * t + 1];
   float* __restrict__ m = (float*)ptrs[4 * t + 2];
   float* __restrict__ v = (float*)ptrs[4 * t + 3];
   const long n = sizes[t];
@@ -107,6 +107,7 @@ __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t*
     m[i] = mi;
     v[i] = vi;
     p[i] = pi - step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    if (zero_grads) g[i] = 0.f;
   }
 }
 extern "C" int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float lr,
@@ -118,7 +119,7 @@ extern "C" int mt_adam_multi(void* const* ptrs, const int64_t* sizes, int count,
   int chunks = (int)((max_size + 256 * 8 - 1) / (256 * 8));
   if (chunks < 1) chunks = 1;
   if (chunks > 2048) chunks = 2048;
-  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, lr, beta1, beta2, eps, wd, bc1, bc2, (const AdamDevState*)nullptr);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, lr, beta1, beta2, eps, wd, bc1, bc2, (const AdamDevState*)nullptr, 0);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -132,14 +133,14 @@ __global__ void adam_tick_kernel(AdamDevState* st, float b1, float b2) {
   st->bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
 }
 extern "C" int mt_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int count, int64_t max_size, float beta1,
-                                 float beta2, float eps, float wd, void* dev_state, mt_stream_t s) {
+                                 float beta2, float eps, float wd, void* dev_state, int zero_grads, mt_stream_t s) {
   if (count == 0) return 0;
   MT_CHECK(dev_state != nullptr, "adam_multi_dev: null state");
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (AdamDevState*)dev_state, beta1, beta2);
   int chunks = (int)((max_size + 256 * 8 - 1) / (256 * 8));
   if (chunks < 1) chunks = 1;
   if (chunks > 2048) chunks = 2048;
-  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, 0.f, beta1, beta2, eps, wd, 1.f, 1.f, (const AdamDevState*)dev_state);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks, count), dim3(256), 0, (hipStream_t)s, ptrs, sizes, 0.f, beta1, beta2, eps, wd, 1.f, 1.f, (const AdamDevState*)dev_state, zero_grads);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -76,7 +76,13 @@ __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__
     const int r = (int)(rt / p.ntaps);
     const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {             // four independent 16-byte loads in flight; added in index order
+      const f32x4 v0 = q[(long)k * (slab >> 2)], v1 = q[(long)(k + 1) * (slab >> 2)];
+      const f32x4 v2 = q[(long)(k + 2) * (slab >> 2)], v3 = q[(long)(k + 3) * (slab >> 2)];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
     float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
 #pragma unroll
     for (int e = 0; e < 4; e++) {

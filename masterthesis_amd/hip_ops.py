@@ -1263,6 +1263,52 @@ def kl_sum(mu, logvar):
     return _KL.apply(mu, logvar)
 
 
+class _LossSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, *terms):
+        w, gid, Wb, Wr = spec
+        n, G = len(terms), len(Wb)
+        ts = [_f32c(t.detach()).reshape(()) for t in terms]
+        dev = ts[0].device
+        out = torch.empty((G + 2,), dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ctx.cw = (C.c_float * n)(*w)
+        ctx.cg = (C.c_int * n)(*gid)
+        ctx.cWb = (C.c_float * G)(*Wb)
+        cWr = (C.c_float * G)(*Wr)
+        L.check(L.load().mt_loss_sum_fwd(ptrs, ctx.cw, ctx.cg, n, ctx.cWb, cWr, G, _ptr(out), _stream()), "mt_loss_sum_fwd")
+        ctx.n, ctx.G = n, G
+        total, logged = out[G], out
+        ctx.mark_non_differentiable(logged)
+        return total, logged
+
+    @staticmethod
+    def backward(ctx, g, _unused=None):
+        d = torch.empty((ctx.n,), dtype=torch.float32, device=g.device)
+        L.check(L.load().mt_loss_sum_bwd(_ptr(_gs(g)), ctx.cw, ctx.cg, ctx.n, ctx.cWb, ctx.G, _ptr(d), _stream()),
+                "mt_loss_sum_bwd")
+        return (None,) + tuple(d[i] for i in range(ctx.n))
+
+
+def loss_sum(groups):
+    """The model's loss expression in ONE launch (and one for its backward) instead of a chain of scalar adds / muls.
+    ``groups``: list of (name, [(scalar tensor, weight), ...], weight in the differentiated total, weight in the reported
+    total).  -> (total [differentiable], {name: group value}, reported total); the group values and the reported total
+    are views of one device buffer (nothing is synchronised)."""
+    w, gid, Wb, Wr, terms, names = [], [], [], [], [], []
+    for g, (name, items, wb, wr) in enumerate(groups):
+        names.append(name)
+        Wb.append(float(wb))
+        Wr.append(float(wr))
+        for t, wt in items:
+            terms.append(t)
+            w.append(float(wt))
+            gid.append(g)
+    total, logged = _LossSum.apply((w, gid, Wb, Wr), *terms)
+    G = len(names)
+    return total, {n: logged[i] for i, n in enumerate(names)}, logged[G + 1]
+
+
 # --------------------------------------------------------------------------------------
 # optimizer step
 # --------------------------------------------------------------------------------------

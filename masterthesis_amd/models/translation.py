@@ -348,7 +348,7 @@ class TranslationModel(Model):
         per-sample independent layers => identical outputs, half the launches, twice the pixels per GEMM) unless
         --dis_sn makes the weights depend on the call."""
         n = fake.shape[0]
-        loss_d_adv, loss_d_cls = 0, 0
+        adv_terms, cls_terms = [], []
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:209; ms_dis goes via gan_loss)
         ragan = getattr(self.args, "use_ragan", False) and not self.args.ms_dis      # (adain_model.py:206-208)
         if getattr(self.args, "dis_sn", False) or getattr(self.args, "dis_norm", None) == "batch":
@@ -363,16 +363,16 @@ class TranslationModel(Model):
                 outs.append((pf, pr, cls[n:]))
         for pf, pr, cr in outs:
             if ragan:
-                loss_d_adv = loss_d_adv + (self.gan_loss(ops.sub_mean(pr, pf), 1) +
-                                           self.gan_loss(ops.sub_mean(pf, pr), 0)) / 2
+                adv_terms += [(self.gan_loss(ops.sub_mean(pr, pf), 1), 0.5), (self.gan_loss(ops.sub_mean(pf, pr), 0), 0.5)]
             elif hinge:
-                loss_d_adv = loss_d_adv + self.gan_loss.hinge_dis(pr, pf)
+                adv_terms += [(ops.hinge_dis(pr, True), 1.0), (ops.hinge_dis(pf, False), 1.0)]
             else:
-                loss_d_adv = loss_d_adv + self.gan_loss(pf, 0) + self.gan_loss(pr, 1)
-            loss_d_cls = loss_d_cls + self.classification_loss(cr, c_org)
-        loss_d = loss_d_adv + self.args.lambda_cls * loss_d_cls
+                adv_terms += [(self.gan_loss(pf, 0), 1.0), (self.gan_loss(pr, 1), 1.0)]
+            cls_terms.append((self.classification_loss(cr, c_org), 1.0))
+        # loss_d = loss_d_adv + lambda_cls * loss_d_cls: one launch for the whole expression (and one in backward)
+        loss_d, v, total = ops.loss_sum([("d_adv", adv_terms, 1.0, 1.0), ("d_cls", cls_terms, self.args.lambda_cls, self.args.lambda_cls)])
         loss_d.backward()
-        self._set_loss(d_adv=loss_d_adv, d_cls=loss_d_cls, d_total=loss_d)
+        self._set_loss(d_adv=v["d_adv"], d_cls=v["d_cls"], d_total=total)
 
     backward_multi_scale_discriminator = backward_discriminator
 
@@ -390,20 +390,22 @@ class TranslationModel(Model):
         self._reduce_and_step(("content_encoder", "decoder"))
 
     def _generator_adv(self, netD, fake, c_org, netD_real=None):
-        adv, cls = 0, 0
+        """-> ([(adversarial term, weight)], [(classification term, weight)]) of the generator loss"""
+        adv, cls = [], []
         hinge = "hinge" in self.args.gan_mode and not self.args.ms_dis     # (adain_model.py:293-295, 367-369)
+        lam = self.args.lambda_cls_G
         if getattr(self.args, "use_ragan", False) and not self.args.ms_dis:
             # relativistic average (286-292, 360-366): real logits from netD_real on the input images
             with ops.frozen(netD, netD_real):
                 pr, _ = netD_real(self.img)
                 pf, cf = netD(fake)
-                adv = (self.gan_loss(ops.sub_mean(pr, pf), 0) + self.gan_loss(ops.sub_mean(pf, pr), 1)) / 2
-                return adv, self.classification_loss(cf, c_org) * self.args.lambda_cls_G
+                adv = [(self.gan_loss(ops.sub_mean(pr, pf), 0), 0.5), (self.gan_loss(ops.sub_mean(pf, pr), 1), 0.5)]
+                return adv, [(self.classification_loss(cf, c_org), lam)]
         with ops.frozen(netD):
             for pf, cf in self._dis_outputs(netD, fake):
-                adv = adv + (self.gan_loss.hinge_gen(pf) if hinge else self.gan_loss(pf, 1))
-                cls = cls + self.classification_loss(cf, c_org)
-        return adv, cls * self.args.lambda_cls_G
+                adv.append((self.gan_loss.hinge_gen(pf) if hinge else self.gan_loss(pf, 1), 1.0))
+                cls.append((self.classification_loss(cf, c_org), lam))
+        return adv, cls
 
     def backward_generator(self, img, c_org):
         a, B = self.args, self.args.batch_size
@@ -427,28 +429,24 @@ class TranslationModel(Model):
         z_s_rec_a, z_s_rec_b = torch.split(z_s_rec, B, dim=0)
         img_recon = self.model.decoder(ops.cat_batch((z_c_rec_a, z_c_rec_b)), torch.cat((z_s_rec_a, z_s_rec_b), dim=0),
                                        torch.cat((cls_a, cls_b), dim=0))
-        loss_g_content = None
+        groups = []
         if a.use_dis_content:
             with ops.frozen(self.model.content_discriminator):
-                loss_g_content = self.backward_content_discriminator(z_c)
-        loss_g_adv, loss_g_cls = self._generator_adv(self.model.discriminator1, img_fake, c_org,
-                                                     netD_real=self.model.discriminator1)
-        loss_g_self = self.l1_loss(img, img_self) * a.lambda_rec
-        loss_g_cc = self.l1_loss(img, img_recon) * a.lambda_rec
-        loss_kl_zc = ops.l2_mean(z_c) * 0.01
+                groups.append(("g_content", [(self.backward_content_discriminator(z_c), 1.0)], 1.0, 1.0))
+        adv, cls = self._generator_adv(self.model.discriminator1, img_fake, c_org, netD_real=self.model.discriminator1)
+        groups += [("g_adv", adv, 1.0, 1.0), ("g_cls", cls, 1.0, 1.0),
+                   ("l1_self_rec", [(self.l1_loss(img, img_self), a.lambda_rec)], 1.0, 1.0),
+                   ("l1_cc_rec", [(self.l1_loss(img, img_recon), a.lambda_rec)], 1.0, 1.0),
+                   ("kl_zc", [(ops.l2_mean(z_c), 0.01)], 1.0, 1.0)]
         if self.reparam:
-            loss_kl_zs = ops.kl_sum(mu, logvar) * 0.01
-            kl_for_grad = loss_kl_zs * float(self.reducer.world)       # batch SUM -> see module docstring
+            # a batch SUM (adain_model.py:313-314): its gradient is scaled by world_size before the mean all-reduce (see
+            # the module docstring); the reported values stay those of this rank's shard
+            groups.append(("kl_zs", [(ops.kl_sum(mu, logvar), 0.01)], float(self.reducer.world), 1.0))
         else:
-            loss_kl_zs = (z_s * z_s).mean() * 0.01
-            kl_for_grad = loss_kl_zs
-        loss_g = loss_g_adv + loss_g_cls + loss_g_self + loss_g_cc + loss_kl_zc
-        if loss_g_content is not None:
-            loss_g = loss_g + loss_g_content
-            self._set_loss(g_content=loss_g_content)
-        (loss_g + kl_for_grad).backward()
-        self._set_loss(g_adv=loss_g_adv, g_cls=loss_g_cls, kl_zc=loss_kl_zc, kl_zs=loss_kl_zs,
-                       l1_self_rec=loss_g_self, l1_cc_rec=loss_g_cc, total_g=(loss_g + loss_kl_zs))
+            groups.append(("kl_zs", [((z_s * z_s).mean(), 0.01)], 1.0, 1.0))
+        loss_g, v, total = ops.loss_sum(groups)
+        loss_g.backward()
+        self._set_loss(total_g=total, **v)
 
     def backward_decoder_random(self, img, c_org):
         a, B = self.args, self.args.batch_size
@@ -461,20 +459,20 @@ class TranslationModel(Model):
         # ... and with --use_ragan the fake logits come from discriminator1, the real ones from discriminator2 (360-362)
         ragan = getattr(a, "use_ragan", False) and not a.ms_dis
         netD = self.model.discriminator1 if (a.ms_dis or ragan) else self.model.discriminator2
-        loss_g_adv2, loss_g_cls2 = self._generator_adv(netD, img_random, c_org, netD_real=self.model.discriminator2)
+        adv, cls = self._generator_adv(netD, img_random, c_org, netD_real=self.model.discriminator2)
         if self.reparam:
             with ops.frozen(self.model.style_encoder):      # Es is not stepped in this phase (235-239)
                 _, mu2, _ = self._encode_style(img_random, c_org)
             mu2_a, mu2_b = torch.split(mu2, B, dim=0)
-            loss_z_l1 = (self.l1_loss(mu2_a, z_sr) + self.l1_loss(mu2_b, z_sr)) * 10
+            lat = [(self.l1_loss(mu2_a, z_sr), 10.0), (self.l1_loss(mu2_b, z_sr), 10.0)]
         else:
             with ops.frozen(self.model.style_encoder):
                 z_rec, _, _ = self._encode_style(img_random, c_org)
             z_rec_a, _ = torch.split(z_rec, B, dim=0)
-            loss_z_l1 = (self.l1_loss(z_rec_a, z_sr) + self.l1_loss(z_rec_a, z_sr)) * 10   # base_model.py:419-420
-        loss_g = loss_z_l1 + loss_g_adv2 + loss_g_cls2
+            lat = [(self.l1_loss(z_rec_a, z_sr), 20.0)]                 # a + a (base_model.py:419-420)
+        loss_g, v, _ = ops.loss_sum([("l1_recon_z", lat, 1.0, 1.0), ("gan2", adv, 1.0, 1.0), ("gan2_cls", cls, 1.0, 1.0)])
         loss_g.backward()
-        self._set_loss(l1_recon_z=loss_z_l1, gan2=loss_g_adv2, gan2_cls=loss_g_cls2)
+        self._set_loss(**v)
 
     # ---- visuals / dispatch ---------------------------------------------------------------------------
     def compute_visuals(self):

@@ -22,6 +22,7 @@ class FusedAdam(torch.optim.Adam):
         self._flat = None
         self._step_count_mt = 0
         self.generation = 0          # bumped whenever the flat buffers are (re)built: captured graphs hold their addresses
+        self._grads_clean = False    # True right after step(): the Adam kernel zeroed the gradients it consumed
         self._dev = None             # 16-byte device record {float lr; int32 step; float bc1; float bc2_sqrt}
         self._dev_lr = None
 
@@ -66,6 +67,7 @@ class FusedAdam(torch.optim.Adam):
         rec.view(torch.int32)[1] = step
         self._dev = rec.to(dev)
         self._dev_lr = None
+        self._grads_clean = False
         self.generation += 1
         ops.bump_epoch(ps)
 
@@ -81,7 +83,11 @@ class FusedAdam(torch.optim.Adam):
 
     # ---- torch.optim API ----
     def zero_grad(self, set_to_none=False):
-        self.flat_grad().zero_()
+        # step() clears the gradient buffer in the pass that reads it: the memset is only needed when something wrote
+        # gradients since (a backward pass whose optimizer step never came) or before the first step
+        if not self._grads_clean:
+            self.flat_grad().zero_()
+        self._grads_clean = False       # (a backward pass is about to write)
         for p in self.params():
             p._mt_pending = 0           # (see hip_ops._Conv: uses whose weight gradient is still to come)
 
@@ -142,8 +148,9 @@ class FusedAdam(torch.optim.Adam):
         # launch argument changes from step to step, so the update can be replayed from a captured hipGraph
         L.check(L.load().mt_adam_multi_dev(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
                                            self._flat[4], float(b1), float(b2), float(g["eps"]),
-                                           float(g["weight_decay"]), C.c_void_p(self._dev.data_ptr()), ops._stream()),
+                                           float(g["weight_decay"]), C.c_void_p(self._dev.data_ptr()), 1, ops._stream()),
                 "mt_adam_multi_dev")
+        self._grads_clean = True
         ops.bump_epoch(self.params())
         ops.repack_params(self.params())    # all cached weight images of this network, one launch
 
