@@ -8,33 +8,19 @@
 // weight (un)packing between the reference layouts and [row][tap][col] tiles
 // ------------------------------------------------------------------------------------------
 // pack[r][t][c] = (r<R && c<C) ? w[r*sr + c*sc + kh[t]*kW + kw[t]] : 0, r<Rp, c<Cp
-// One thread owns a (row, column pair) and walks the taps: its reads run along the filter taps of ONE (r, c)
-// element (contiguous in the reference layouts, so the cache line it touched serves all taps; the element-per-thread
-// mapping fetched every line once per tap: 614 MB of L2 traffic for a 63 MB discriminator), its writes are 4-byte
-// (bf16 pair) / 8-byte stores that adjacent threads make contiguous.
-template <bool BF16>
-__device__ __forceinline__ void pack_pairs(const float* __restrict__ w, void* __restrict__ out, const PackParams& p,
-                                           long first, long step) {
-  const int cpn = p.Cp >> 1;
-  const long pairs = (long)p.Rp * cpn;
-  for (long i = first; i < pairs; i += step) {
-    const int c = (int)(i % cpn) * 2;
-    const int r = (int)(i / cpn);
-    const bool v0 = r < p.R && c < p.C, v1 = r < p.R && c + 1 < p.C;
-    const float* s0 = w + (long)r * p.sr + (long)c * p.sc;
-    const float* s1 = s0 + p.sc;
-    const long o = ((long)r * p.ntaps) * p.Cp + c;
-    for (int t = 0; t < p.ntaps; t++) {
-      const int off = p.kh[t] * p.kW + p.kw[t];
-      const float a = v0 ? s0[off] : 0.f, b = v1 ? s1[off] : 0.f;
-      if constexpr (BF16) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + o + (long)t * p.Cp) = pack2_bf16(a, b);
-      else *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + o + (long)t * p.Cp) = make_float2(a, b);
-    }
-  }
-}
 template <bool BF16>
 __global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out, PackParams p) {
-  pack_pairs<BF16>(w, out, p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if constexpr (BF16) reinterpret_cast<unsigned short*>(out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(out)[i] = v;
+  }
 }
 // batched variant: the table lives in device memory (built once per network, addresses are stable)
 __global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
@@ -44,9 +30,19 @@ __global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
     if ((int)blockIdx.x >= tab[mid].blk0) lo = mid; else hi = mid - 1;
   }
   const PackEntry& e = tab[lo];
-  const long first = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x, step = (long)e.nblk * blockDim.x;
-  if (e.bf16) pack_pairs<true>(e.w, e.out, e.p, first, step);
-  else pack_pairs<false>(e.w, e.out, e.p, first, step);
+  const PackParams& p = e.p;
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  const float* __restrict__ w = e.w;
+  for (long i = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; i < total; i += (long)e.nblk * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(e.out)[i] = v;
+  }
 }
 int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s) {
   if (n <= 0 || total_blocks <= 0) return 0;
@@ -55,8 +51,8 @@ int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hi
   return 0;
 }
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s) {
-  const long total = (long)p.Rp * (p.Cp >> 1);      // (row, column pair) threads
-  if (total == 0 || p.ntaps == 0) return 0;
+  const long total = (long)p.Rp * p.ntaps * p.Cp;
+  if (total == 0) return 0;
   const int blocks = (int)min((long)4096, (total + 255) / 256);
   if (dtype == MT_BF16) hipLaunchKernelGGL((pack_kernel<true>), dim3(blocks), dim3(256), 0, s, w, out, p);
   else hipLaunchKernelGGL((pack_kernel<false>), dim3(blocks), dim3(256), 0, s, w, out, p);
