@@ -9,4 +9,4 @@ for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_
   n=${pass%%:*}; c=${pass#*:}
   rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$n -o $n --output-format csv -- python3 $R/tools/bench_k1.py > $R/gpurun_out/pmc_$n.log 2>&1
 done
-cd $R && python3 tools/pmc_k1_json.py
+cd $R && python3 tools/pmc_k1_json.py ${1:-profiles/round2_k1_fwd_pmc.json}
