@@ -160,6 +160,12 @@ int mt_act_fwd(int dtype, const void* x, void* y, size_t n, int act, float slope
 /* dx = dy * act'(.) evaluated from the activation OUTPUT y. */
 int mt_act_bwd(int dtype, const void* dy, const void* y, void* dx, size_t n, int act,
                float slope, mt_stream_t s);
+/* act_bwd and the bias gradient in one pass over dy (convolutions with a fused activation): dz = dy * act'(y),
+ * dbias[c] (+)= sum_pixels dz[pixel][c] (fp32 [C]; block partials in ws, added in block order -- reproducible).
+ * ws: mt_act_bwd_bias_ws_bytes(Cp) bytes. */
+size_t mt_act_bwd_bias_ws_bytes(int Cp);
+int mt_act_bwd_bias(int dtype, const void* dy, const void* y, void* dz, size_t npix, int Cp, int C, int act,
+                    float slope, float* dbias, int accumulate, void* ws, size_t ws_bytes, mt_stream_t s);
 int mt_add(int dtype, const void* a, const void* b, void* y, size_t n, mt_stream_t s);
 /* y = x + noise (misc.py:22-26).  noise given (parity mode) ... */
 /* ... or generated on device: Philox4x32-10 + Box-Muller, N(0,1), counter = element index. */

@@ -128,9 +128,12 @@ int mt_launch_ring_fold(int dtype, const void* src, void* dst, int N, int H, int
 // bias gradient: db[c] = sum over pixels of dy[pixel][c].  Two launches, no atomics (512 blocks adding into
 // the same C addresses serialise: ~100 us): blocks write fp32 partial rows, a small kernel adds them up.
 // ------------------------------------------------------------------------------------------
-template <bool BF16>
+// ACT: the same pass also applies the activation derivative (g = dy * act'(y), from the saved OUTPUT y of a convolution
+// with a fused activation), writes g and sums g -- act_bwd + bias gradient in one read of dy instead of two.
+template <bool BF16, bool ACT>
 __global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ dy, float* __restrict__ part, long npix,
-                                                     long cchunks_, long pix_per_block) {
+                                                     long cchunks_, long pix_per_block, const u32x4* __restrict__ y,
+                                                     u32x4* __restrict__ dz, int act, float slope) {
   constexpr int V = Elem<BF16>::V;
   __shared__ float red[256];
   const int cchunks = (int)cchunks_;
@@ -145,22 +148,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u32x4* __restrict__ d
   if (pl < npl) {
     // 4 independent 16-byte loads in flight per thread (a dependent one-at-a-time loop is latency bound)
     long px = p0 + pl;
+    auto masked = [&](long idx, const u32x4& gv, const u32x4& yv, float* f) {
+      Elem<BF16>::unpack(gv, f);
+      if constexpr (ACT) {
+        float o[V];
+        Elem<BF16>::unpack(yv, o);
+#pragma unroll
+        for (int e = 0; e < V; e++) f[e] *= act_grad_y(o[e], act, slope);
+        dz[idx] = Elem<BF16>::pack(f);
+      }
+    };
     for (; px + 3 * (long)npl < p1; px += 4 * (long)npl) {
-      const u32x4 v0 = dy[px * cchunks + cq];
-      const u32x4 v1 = dy[(px + npl) * cchunks + cq];
-      const u32x4 v2 = dy[(px + 2 * (long)npl) * cchunks + cq];
-      const u32x4 v3 = dy[(px + 3 * (long)npl) * cchunks + cq];
+      const long i0 = px * cchunks + cq, i1 = (px + npl) * cchunks + cq, i2 = (px + 2 * (long)npl) * cchunks + cq,
+                 i3 = (px + 3 * (long)npl) * cchunks + cq;
+      const u32x4 v0 = dy[i0], v1 = dy[i1], v2 = dy[i2], v3 = dy[i3];
+      u32x4 y0 = v0, y1 = v1, y2 = v2, y3 = v3;
+      if constexpr (ACT) { y0 = y[i0]; y1 = y[i1]; y2 = y[i2]; y3 = y[i3]; }
       float f0[V], f1[V], f2[V], f3[V];
-      Elem<BF16>::unpack(v0, f0);
-      Elem<BF16>::unpack(v1, f1);
-      Elem<BF16>::unpack(v2, f2);
-      Elem<BF16>::unpack(v3, f3);
+      masked(i0, v0, y0, f0);
+      masked(i1, v1, y1, f1);
+      masked(i2, v2, y2, f2);
+      masked(i3, v3, y3, f3);
 #pragma unroll
       for (int e = 0; e < V; e++) accv[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
     }
     for (; px < p1; px += npl) {
+      const long i0 = px * cchunks + cq;
+      const u32x4 v0 = dy[i0];
+      u32x4 y0 = v0;
+      if constexpr (ACT) y0 = y[i0];
       float f[V];
-      Elem<BF16>::unpack(dy[px * cchunks + cq], f);
+      masked(i0, v0, y0, f);
 #pragma unroll
       for (int e = 0; e < V; e++) accv[e] += f[e];
     }
@@ -200,8 +218,23 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
   }
 }
 size_t mt_colsum_ws_bytes(int Cp) { return (size_t)512 * Cp * sizeof(float); }
+static int launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
+                         size_t ws_bytes, hipStream_t s, const void* y, void* dz, int act, float slope);
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
                      size_t ws_bytes, hipStream_t s) {
+  return launch_colsum(dtype, dy, db, npix, Cp, C, accumulate, ws, ws_bytes, s, nullptr, nullptr, 0, 0.f);
+}
+// dz = dy * act'(y) and dbias[c] (+)= sum over pixels of dz[pixel][c] in one pass (act_bwd + the bias gradient of a
+// convolution with a fused activation: networks.py:363-371 discriminator stacks, blocks.py:109-117 style encoder)
+extern "C" size_t mt_act_bwd_bias_ws_bytes(int Cp) { return mt_colsum_ws_bytes(Cp); }
+extern "C" int mt_act_bwd_bias(int dtype, const void* dy, const void* y, void* dz, size_t npix, int Cp, int C, int act,
+                               float slope, float* dbias, int accumulate, void* ws, size_t ws_bytes, mt_stream_t st) {
+  MT_CHECK(dy != nullptr && y != nullptr && dz != nullptr && dbias != nullptr, "act_bwd_bias: null argument");
+  MT_CHECK(Cp % 8 == 0 && C <= Cp, "act_bwd_bias: bad channel counts %d / %d", C, Cp);
+  return launch_colsum(dtype, dy, dbias, (long)npix, Cp, C, accumulate, ws, ws_bytes, (hipStream_t)st, y, dz, act, slope);
+}
+static int launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
+                         size_t ws_bytes, hipStream_t s, const void* y, void* dz, int act, float slope) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(cchunks <= 256, "colsum: too many channels %d", Cp);
@@ -214,12 +247,23 @@ int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, in
   ppb = (ppb + npl - 1) / npl * npl;
   const int blocks = (int)((npix + ppb - 1) / ppb);
   if (blocks > 0) {
-    if (dtype == MT_BF16)
-      hipLaunchKernelGGL((colsum_kernel<true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
-                         (long)cchunks, ppb);
-    else
-      hipLaunchKernelGGL((colsum_kernel<false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
-                         (long)cchunks, ppb);
+    const u32x4* yq = (const u32x4*)y;
+    u32x4* zq = (u32x4*)dz;
+    if (y != nullptr) {
+      if (dtype == MT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<true, true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                           (long)cchunks, ppb, yq, zq, act, slope);
+      else
+        hipLaunchKernelGGL((colsum_kernel<false, true>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                           (long)cchunks, ppb, yq, zq, act, slope);
+    } else {
+      if (dtype == MT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<true, false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                           (long)cchunks, ppb, yq, zq, act, slope);
+      else
+        hipLaunchKernelGGL((colsum_kernel<false, false>), dim3(blocks), dim3(threads), 0, s, (const u32x4*)dy, (float*)ws, npix,
+                           (long)cchunks, ppb, yq, zq, act, slope);
+    }
     MT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const float*)ws, db, blocks, Cp, C,

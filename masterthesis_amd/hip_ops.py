@@ -433,13 +433,28 @@ class _Conv(torch.autograd.Function):
             _grad_use_done(ctx)
             return None, None, None, None
         dy = canon(dy)
+        dx = dw = db = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gb = _fused_grad_target(ctx.bias_owner) if want_b else None
+        bias_done = False
         if desc.act != L.ACT_NONE:
             dz = new_act(*dy.shape, dy.dtype, dy.device)
-            n = dy.shape[0] * dy.shape[2] * dy.shape[3] * padc(dy.shape[1])
-            L.check(lib.mt_act_bwd(desc.dtype, _ptr(dy), _ptr(y), _ptr(dz), n, desc.act, desc.slope, _stream()),
-                    "mt_act_bwd")
+            Cp = padc(dy.shape[1])
+            npix = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            if want_b:
+                # activation derivative and bias gradient in ONE pass over dy
+                nws = int(lib.mt_act_bwd_bias_ws_bytes(Cp))
+                ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+                if gb is None:
+                    db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
+                L.check(lib.mt_act_bwd_bias(desc.dtype, _ptr(dy), _ptr(y), _ptr(dz), npix, Cp, desc.Co, desc.act, desc.slope,
+                                            _ptr(gb if gb is not None else db), int(gb is not None), _ptr(ws), nws, _stream()),
+                        "mt_act_bwd_bias")
+                bias_done = True
+            else:
+                L.check(lib.mt_act_bwd(desc.dtype, _ptr(dy), _ptr(y), _ptr(dz), npix * Cp, desc.act, desc.slope, _stream()),
+                        "mt_act_bwd")
             dy = dz
-        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             pack = _get_pack(ctx.owner, weight, desc, L.PACK_BWD_DATA)
             nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
@@ -448,25 +463,25 @@ class _Conv(torch.autograd.Function):
             with _oplog("dgrad", desc):
                 L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
                         "mt_conv_bwd_data")
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_b:
+        need_b = want_b and not bias_done           # bias gradient still to be taken by the weight-gradient call
+        if ctx.needs_input_grad[1] or need_b:
             nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
             ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
-            gb = _fused_grad_target(ctx.bias_owner) if want_b else None
-            if gw is not None and (gb is not None or not want_b):
+            gbw = gb if need_b else None
+            if gw is not None and (gbw is not None or not need_b):
                 # accumulate in place; autograd gets None for both
-                with _oplog("wgrad", desc, (int(want_b),)):
-                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gb), _ptr(ws), nws,
+                with _oplog("wgrad", desc, (int(need_b),)):
+                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), _ptr(gbw), _ptr(ws), nws,
                                                    1, _stream()), "mt_conv_bwd_weight")
             else:
                 dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
-                if want_b:
+                if need_b:
                     db = torch.empty((desc.Co,), dtype=torch.float32, device=dy.device)
-                with _oplog("wgrad", desc, (int(want_b),)):
-                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws,
-                                                   0, _stream()), "mt_conv_bwd_weight")
+                with _oplog("wgrad", desc, (int(need_b),)):
+                    L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db if need_b else None),
+                                                   _ptr(ws), nws, 0, _stream()), "mt_conv_bwd_weight")
         _grad_use_done(ctx)
         return dx, dw, db, None
 
