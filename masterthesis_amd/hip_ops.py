@@ -491,7 +491,14 @@ def _grad_use_done(ctx):
         return
     owner = ctx.owner
     owner._mt_pending = getattr(owner, "_mt_pending", 1) - 1
-    if owner._mt_pending == 0:
+    if owner._mt_pending < 0:
+        # more weight-gradient launches than recorded uses: a bucket would have been exchanged too early
+        hooked = getattr(owner, "_mt_ready_hook", None) is not None
+        owner._mt_pending = 0
+        if hooked:
+            raise RuntimeError("gradient-ready bookkeeping underflow: a weight was used in a graph recorded before its "
+                               "use counter was reset (FusedAdam.reset_pending)")
+    elif owner._mt_pending == 0:
         hook = getattr(owner, "_mt_ready_hook", None)
         if hook is not None:
             hook(owner)
@@ -584,6 +591,10 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.owners = (weight, bias)
+        ctx.owner = weight
+        ctx.counted = bool(weight.requires_grad and weight.is_leaf and torch.is_grad_enabled())   # (see _Conv.forward)
+        if ctx.counted:
+            weight._mt_pending = getattr(weight, "_mt_pending", 0) + 1
         return y
 
     @staticmethod
@@ -601,11 +612,13 @@ class _Linear(torch.autograd.Function):
             # accumulate straight into param.grad; autograd receives None for both
             L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(gw), _ptr(gb), n, i, o, 1,
                                            _stream()), "mt_linear_bwd")
+            _grad_use_done(ctx)
             return dx, None, None
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty((o,), dtype=torch.float32, device=x.device) if want_b else None
         L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), n, i, o, 0,
                                        _stream()), "mt_linear_bwd")
+        _grad_use_done(ctx)
         return dx, (dw if ctx.needs_input_grad[1] else None), db
 
 

@@ -189,12 +189,17 @@ class TranslationModel(Model):
         fake = self.model.decoder(ops.cat_batch(contents), torch.cat(styles, dim=0), torch.cat(classes, dim=0))
         return torch.split(fake, B, dim=0)
 
-    def _reduce_and_step(self, names):
+    def _reduce_and_step(self, names, early=None):
+        """exchange (what the backward pass has not already sent) + Adam step of every network of a phase"""
         self._mark("exchange " + "+".join(names))
         opts = [self.optimizer[n] for n in names]
-        handles = self.reducer.reduce([o.flat_grad() for o in opts])
-        for o, h in zip(opts, handles):
-            self.reducer.wait(h)
+        if early is None:
+            handles = [[h] for h in self.reducer.reduce([o.flat_grad() for o in opts])]
+        else:
+            handles = [self._finish_early_exchange(n, early[n]) for n in names]
+        for o, hs in zip(opts, handles):
+            for h in hs:
+                self.reducer.wait(h)
             o.step()
 
     # ---- inference surface (reference adain_model.py:96-134) --------------------------------------
@@ -273,9 +278,9 @@ class TranslationModel(Model):
             self._mark(name)
             opt = self.optimizer[name]
             opt.zero_grad()
-            early = self._arm_early_exchange(opt)
+            early = self._arm_early_exchange(name, nbuckets=2)
             self.backward_discriminator(self.model[name], img, fake, c_org)
-            pending.append((opt, self._finish_early_exchange(opt, early)))
+            pending.append((opt, self._finish_early_exchange(name, early)))
         # discriminator1 is needed by phase 3; discriminator2 only by phase 4, so with a live exchange its wait + Adam
         # step move in front of phase 4 and its all-reduce also hides behind the whole of phase 3
         (opt1, h1), d2 = pending
@@ -298,21 +303,48 @@ class TranslationModel(Model):
         if self.reducer.log is not None:
             self.reducer.log.append(("phase", what))
 
-    # ---- exchange that starts inside the backward pass (discriminator phases) -----------------------------
-    def _arm_early_exchange(self, opt):
-        """Bucketed all-reduce launched from the backward pass itself: as soon as the last weight-gradient kernel of a
-        bucket has been enqueued (hip_ops.set_grad_ready_hook), its slice of the flat gradient buffer goes to the side
-        stream -- for a discriminator the 9.4 M-parameter last convolution is produced FIRST, so most of the exchange
-        runs under the rest of the backward pass.  Needs every parameter's gradient to be accumulated by our own
-        backward kernels (plain convolution stacks: not with spectral norm or BatchNorm holders)."""
-        a = self.args
-        if not self.reducer.enabled or getattr(a, "dis_sn", False) or getattr(a, "dis_norm", None) is not None \
-                or os.environ.get("MT_NO_EARLY_EXCHANGE", "0") == "1":
+    # ---- exchange that starts inside the backward pass ----------------------------------------------------
+    def _gradient_sources(self, name):
+        """How each parameter of network ``name`` receives its gradient: "kernel" = accumulated straight into the flat
+        buffer by our backward kernels (convolution / linear weights; their biases ride on the same launch), "autograd" =
+        through autograd's AccumulateGrad (LayerNorm / BatchNorm affine parameters).  None if the network has parameters
+        we cannot track (spectral-norm holders: the kernels see weight_orig / sigma, a non-leaf)."""
+        cache = self.__dict__.setdefault("_grad_sources", {})
+        if name not in cache:
+            import torch.nn as nn
+            kernel, rides, auto, ok = [], set(), [], True
+            for m in self.model[name].modules():
+                if hasattr(m, "weight_orig"):
+                    ok = False
+                own = dict(m.named_parameters(recurse=False))
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                    if "weight" in own:
+                        kernel.append(own["weight"])
+                    if "bias" in own:
+                        rides.add(id(own["bias"]))
+                else:
+                    auto += list(own.values())
+            cache[name] = (kernel, rides, auto) if ok else None
+        return cache[name]
+
+    def _arm_early_exchange(self, name, nbuckets=2):
+        """Bucketed all-reduce launched from the backward pass itself: as soon as the last gradient contribution of every
+        parameter of a bucket has been enqueued, its slice of the flat gradient buffer goes to the side stream.  For a
+        discriminator the 9.4 M-parameter last convolution is produced FIRST, so most of the exchange runs under the rest
+        of the backward pass; in the generator phases the decoder's buffer travels under the encoders' backward.
+        "Last contribution enqueued" = the per-weight use counter of hip_ops returned to zero (kernel-accumulated
+        parameters) or autograd's post-accumulate hook fired (affine norm parameters)."""
+        opt = self.optimizer[name]
+        src = self._gradient_sources(name) if self.reducer.enabled else None
+        if src is None or os.environ.get("MT_NO_EARLY_EXCHANGE", "0") == "1":
             return None
-        state = {"handles": [], "buckets": []}
+        kernel, rides, auto = src
+        tracked = {id(p) for p in kernel} | {id(p) for p in auto}
+        state = {"handles": [], "buckets": [], "params": []}
         flat = opt.flat_grad()
-        for lo, hi, members in opt.grad_buckets():
-            b = {"lo": lo, "hi": hi, "left": len(members), "sent": False}
+        for lo, hi, members in opt.grad_buckets(nbuckets):
+            mem = [p for p in members if id(p) in tracked]
+            b = {"lo": lo, "hi": hi, "left": len(mem), "sent": False}
             state["buckets"].append(b)
 
             def ready(_p, b=b):
@@ -320,19 +352,25 @@ class TranslationModel(Model):
                 if b["left"] == 0 and not b["sent"]:
                     b["sent"] = True
                     state["handles"] += self.reducer.reduce([flat[b["lo"]:b["hi"]]])
-            for p in members:
+            for p in mem:
                 ops.set_grad_ready_hook(p, ready)
-            state.setdefault("params", []).extend(members)
+            state["params"] += mem
+        for p in auto:
+            if not getattr(p, "_mt_post_hooked", False):       # registered once; dispatches to whatever is armed
+                p.register_post_accumulate_grad_hook(
+                    lambda q: (getattr(q, "_mt_ready_hook", None) or (lambda _q: None))(q))
+                p._mt_post_hooked = True
         return state
 
-    def _finish_early_exchange(self, opt, state):
+    def _finish_early_exchange(self, name, state):
         """-> the handles the optimizer step has to wait for"""
+        opt = self.optimizer[name]
         if state is None:
             return self.reducer.reduce([opt.flat_grad()])
-        for p in state.get("params", []):
+        for p in state["params"]:
             ops.set_grad_ready_hook(p, None)
         flat = opt.flat_grad()
-        for b in state["buckets"]:              # (a bucket none of whose weights was used in this graph)
+        for b in state["buckets"]:              # (a bucket with a parameter that was not used in this graph)
             if not b["sent"]:
                 b["sent"] = True
                 state["handles"] += self.reducer.reduce([flat[b["lo"]:b["hi"]]])
@@ -379,15 +417,21 @@ class TranslationModel(Model):
     # ---- PHASE 3-4 ----------------------------------------------------------------------------------
     @ops.step_scope
     def update_generator(self, img, c_org):
-        for n in ("content_encoder", "style_encoder", "decoder"):
+        names = ("content_encoder", "style_encoder", "decoder")
+        self._mark("phase3")
+        for n in names:
             self.optimizer[n].zero_grad()
+        early = {n: self._arm_early_exchange(n, nbuckets=1) for n in names}    # a network's buffer leaves when it is complete
         self.backward_generator(img, c_org)
-        self._reduce_and_step(("content_encoder", "style_encoder", "decoder"))
+        self._reduce_and_step(names, early)
         self._finish_deferred()                 # discriminator2's step (deferred by update_discriminator)
-        for n in ("content_encoder", "decoder"):
+        names = ("content_encoder", "decoder")
+        self._mark("phase4")
+        for n in names:
             self.optimizer[n].zero_grad()
+        early = {n: self._arm_early_exchange(n, nbuckets=1) for n in names}
         self.backward_decoder_random(img, c_org)
-        self._reduce_and_step(("content_encoder", "decoder"))
+        self._reduce_and_step(names, early)
 
     def _generator_adv(self, netD, fake, c_org, netD_real=None):
         """-> ([(adversarial term, weight)], [(classification term, weight)]) of the generator loss"""
@@ -497,6 +541,9 @@ class TranslationModel(Model):
         return self._optimize_eager(global_iter)
 
     def _optimize_eager(self, global_iter):
+        if self.reducer.enabled:
+            for opt in self.optimizer.values():
+                opt.reset_pending()
         if self.args.use_dis_content and global_iter % self.args.d_iter != 0:
             self.update_content_discriminator(self.img, self.c_org)
             return

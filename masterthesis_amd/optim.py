@@ -88,8 +88,13 @@ class FusedAdam(torch.optim.Adam):
         if not self._grads_clean:
             self.flat_grad().zero_()
         self._grads_clean = False       # (a backward pass is about to write)
+
+    def reset_pending(self):
+        """forget weight uses of graphs that were never run backward (see hip_ops._Conv.forward); called at the top of
+        a training iteration, NOT by zero_grad: the encoder pass shared between the discriminator update and phase 3 is
+        recorded before phase 3 zeroes the gradients"""
         for p in self.params():
-            p._mt_pending = 0           # (see hip_ops._Conv: uses whose weight gradient is still to come)
+            p._mt_pending = 0
 
     def grad_buckets(self, nbuckets=2, min_elems=None):
         """Split the flat gradient buffer at parameter boundaries into up to ``nbuckets`` contiguous ranges, LAST
@@ -116,7 +121,7 @@ class FusedAdam(torch.optim.Adam):
         out = []
         for hi, lo in zip(bounds[:-1], bounds[1:]):
             if hi > lo:
-                members = [p for p, o in zip(ps, offs) if lo <= o < hi and p.dim() > 1]
+                members = [p for p, o in zip(ps, offs) if lo <= o < hi]
                 out.append((lo, hi, members))
         return out
 

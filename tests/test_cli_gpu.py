@@ -159,8 +159,8 @@ def test_rccl_exchange_path_single_rank(comm, tmp_path, hip_device, monkeypatch)
                 ev = log[it * per_step:(it + 1) * per_step]
                 kinds = [e[0] if e[0] != "phase" else e[1] for e in ev]
                 # discriminator phases: two bucket exchanges each, issued before the next phase is entered
-                i1, i2 = kinds.index("discriminator1"), kinds.index("discriminator2")
-                i3 = kinds.index("exchange content_encoder+style_encoder+decoder")
+                i1, i2, i3 = kinds.index("discriminator1"), kinds.index("discriminator2"), kinds.index("phase3")
+                i4 = kinds.index("phase4")
                 r1 = [e[1] for e in ev[i1:i2] if e[0] == "reduce"]
                 r2 = [e[1] for e in ev[i2:i3] if e[0] == "reduce"]
                 assert len(r1) == 2 and len(r2) == 2, (r1, r2)
@@ -168,10 +168,15 @@ def test_rccl_exchange_path_single_rank(comm, tmp_path, hip_device, monkeypatch)
                 # discriminator1 is stepped (1 wait per bucket) before phase 3; discriminator2's waits come after the
                 # phase-3 exchange was enqueued (its step is deferred to the start of phase 4)
                 assert kinds[i2:i3].count("wait") == 2
-                i4 = kinds.index("exchange content_encoder+decoder")
-                assert [e[1] for e in ev[i3:i4] if e[0] == "reduce"] == [[M.optimizer[n].flat_grad().numel() for n in
-                                                                         ("content_encoder", "style_encoder", "decoder")]]
-                assert kinds[i3:i4].count("wait") == 3 + 2
+                sizes = {n: M.optimizer[n].flat_grad().numel() for n in ("content_encoder", "style_encoder", "decoder")}
+                p3 = ev[i3:i4]
+                assert sorted(e[1][0] for e in p3 if e[0] == "reduce") == sorted(sizes.values())
+                assert [k for k in kinds[i3:i4] if k == "wait"] == ["wait"] * (3 + 2)
+                # ... and the decoder's buffer leaves from INSIDE the backward pass: before the phase's exchange point
+                ix = kinds.index("exchange content_encoder+style_encoder+decoder")
+                early = [e[1][0] for e in ev[i3:ix] if e[0] == "reduce"]
+                assert sizes["decoder"] in early, early
+                assert sorted(e[1][0] for e in ev[i4:] if e[0] == "reduce") == sorted([sizes["content_encoder"], sizes["decoder"]])
         if M.reducer.native is not None:
             M.reducer.native.close()
         return out
