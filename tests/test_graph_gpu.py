@@ -135,3 +135,35 @@ def test_deterministic_mode_is_bit_reproducible(tmp_path, hip_device):
         assert torch.equal(p0, p1), "parameters differ between two identical-seed deterministic runs"
     finally:
         ops.set_deterministic(False)
+
+
+def test_inference_graph_matches_eager(tmp_path, hip_device):
+    """forward_random / forward_reference replayed from a hipGraph (--hip_graph, eval mode so no noise is drawn): same
+    output as the eager call, for changing inputs."""
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd import models
+    outs = {}
+    for graph in (False, True):
+        a = _args(str(tmp_path), graph, mode="test", precision="bf16", num_domains=4, batch_size=1)
+        torch.manual_seed(5)
+        M = models.AdaINModel(a)
+        M.initialize()
+        for net in M.model:
+            M.model[net].eval()
+        res = []
+        with torch.no_grad():
+            for k in range(5):
+                g = torch.Generator().manual_seed(100 + k)
+                img = (torch.rand(1, 3, 96, 160, generator=g) * 2 - 1).to(hip_device)
+                z = torch.randn(1, 8, generator=g).to(hip_device)
+                c = torch.eye(4)[[k % 4]].to(hip_device)
+                r, _, _ = M.forward_random(img, z, c)
+                res.append(ops.to_nchw_f32(r).clone())
+                f, _, _ = M.forward_reference(img, img.flip(3), c)
+                res.append(ops.to_nchw_f32(f).clone())
+        outs[graph] = res
+        if graph:
+            assert sum("graph" in st for st in M._infer_graphs.values()) == 2
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == (1, 3, 96, 160)
+        assert torch.equal(a, b), f"graphed inference differs: max {(a - b).abs().max().item():.3e}"

@@ -19,12 +19,14 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--hip_graph", action="store_true", help="replay the forwards from captured hipGraphs")
     o = ap.parse_args()
     from masterthesis_amd import models
     dev = torch.device("cuda", 0)
     a = argparse.Namespace(mode="test", precision=o.precision, input_dim=3, dim=64, enc_norm="instance", num_domains=4,
                            latent_dim=8, up_type="transpose", dec_norm="layer", use_dropout=False, init_type="normal",
-                           init_gain=0.02, resume=None, gpu_ids=[0], batch_size=o.batch_size, concat=False, reparam=False)
+                           init_gain=0.02, resume=None, gpu_ids=[0], batch_size=o.batch_size, concat=False, reparam=False,
+                           hip_graph=o.hip_graph)
     torch.manual_seed(0)
     M = models.AdaINModel(a)
     M.initialize()
@@ -42,7 +44,7 @@ def main():
                 fn()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / o.iters
-        print(f"{name}: {dt * 1e3:.2f} ms per batch of {o.batch_size} at {o.height}x{o.width} ({o.precision}) = "
+        print(f"{name}{' [hipGraph]' if o.hip_graph else ''}: {dt * 1e3:.2f} ms per batch of {o.batch_size} at {o.height}x{o.width} ({o.precision}) = "
               f"{o.batch_size / dt:.1f} images/s")
 
 
