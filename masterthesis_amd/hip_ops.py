@@ -410,7 +410,8 @@ class _Conv(torch.autograd.Function):
         # uses of this weight whose weight gradient is still to come in the backward pass under construction: when the
         # count returns to zero the parameter's gradient is final (it is accumulated straight into param.grad), which
         # is what lets the data-parallel exchange of a bucket start INSIDE the backward pass (set_grad_ready_hook)
-        ctx.counted = bool(owner.requires_grad and owner.is_leaf and torch.is_grad_enabled())
+        # (grad mode is always off INSIDE Function.forward: the caller's mode travels in cfg[9])
+        ctx.counted = bool(len(cfg) > 9 and cfg[9] and owner.requires_grad and owner.is_leaf)
         if ctx.counted:
             owner._mt_pending = getattr(owner, "_mt_pending", 0) + 1
         # the statistics output never carries a gradient: without this autograd materialises a zero tensor for it
@@ -519,13 +520,13 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slo
     affine-free InstanceNorm the bias gradient is identically zero (the reference computes round-off there)."""
     pm = L.PAD_REFLECT if (pad_mode == "reflect" and pad > 0) else L.PAD_ZERO
     return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0, bool(stats),
-                                         bool(bias_grad)))
+                                         bool(bias_grad), torch.is_grad_enabled()))
 
 
 def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
     """nn.ConvTranspose2d (+ activation); weight layout [Cin, Cout, kh, kw]."""
     return _Conv.apply(x, weight, bias, (stride, pad, L.PAD_ZERO, _act_code(act), float(slope), True, out_pad, False,
-                                         True))
+                                         True, torch.is_grad_enabled()))
 
 
 class _SpectralScale(torch.autograd.Function):
@@ -577,7 +578,7 @@ def spectral_norm_weight(weight_orig, u, v, training=True, n_power_iterations=1,
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, grad_on=False):
         x = _f32c(x)
         w = _f32c(weight.detach())
         b = None if bias is None else _f32c(bias.detach())
@@ -592,7 +593,7 @@ class _Linear(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.owners = (weight, bias)
         ctx.owner = weight
-        ctx.counted = bool(weight.requires_grad and weight.is_leaf and torch.is_grad_enabled())   # (see _Conv.forward)
+        ctx.counted = bool(grad_on and weight.requires_grad and weight.is_leaf)   # (see _Conv.forward)
         if ctx.counted:
             weight._mt_pending = getattr(weight, "_mt_pending", 0) + 1
         return y
@@ -613,17 +614,17 @@ class _Linear(torch.autograd.Function):
             L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(gw), _ptr(gb), n, i, o, 1,
                                            _stream()), "mt_linear_bwd")
             _grad_use_done(ctx)
-            return dx, None, None
+            return dx, None, None, None
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty((o,), dtype=torch.float32, device=x.device) if want_b else None
         L.check(L.load().mt_linear_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), n, i, o, 0,
                                        _stream()), "mt_linear_bwd")
         _grad_use_done(ctx)
-        return dx, (dw if ctx.needs_input_grad[1] else None), db
+        return dx, (dw if ctx.needs_input_grad[1] else None), db, None
 
 
 def linear(x, weight, bias=None):
-    return _Linear.apply(x, weight, bias)
+    return _Linear.apply(x, weight, bias, torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------

@@ -315,6 +315,7 @@ class TranslationModel(Model):
             opt.zero_grad()
             early = self._arm_early_exchange(name, nbuckets=2)
             self.backward_discriminator(self.model[name], img, fake, c_org)
+            self._mark("backward done " + name)
             pending.append((opt, self._finish_early_exchange(name, early)))
         # discriminator1 is needed by phase 3; discriminator2 only by phase 4, so with a live exchange its wait + Adam
         # step move in front of phase 4 and its all-reduce also hides behind the whole of phase 3

@@ -165,6 +165,10 @@ def test_rccl_exchange_path_single_rank(comm, tmp_path, hip_device, monkeypatch)
                 r2 = [e[1] for e in ev[i2:i3] if e[0] == "reduce"]
                 assert len(r1) == 2 and len(r2) == 2, (r1, r2)
                 assert sum(x[0] for x in r1) == n_d and r1[0][0] > r1[1][0], r1        # the big tail bucket goes first
+                # ... and BOTH leave from inside the backward pass (the second with the first layer's weight gradient)
+                for nm, lo in (("discriminator1", i1), ("discriminator2", i2)):
+                    done = kinds.index("backward done " + nm)
+                    assert kinds[lo:done].count("reduce") == 2, kinds[lo:done + 1]
                 # discriminator1 is stepped (1 wait per bucket) before phase 3; discriminator2's waits come after the
                 # phase-3 exchange was enqueued (its step is deferred to the start of phase 4)
                 assert kinds[i2:i3].count("wait") == 2
