@@ -363,7 +363,7 @@ class _oplog:
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
-        stride, pad, pad_mode, act, slope, transposed, out_pad, want_stats, bias_grad = cfg
+        stride, pad, pad_mode, act, slope, transposed, out_pad, want_stats, bias_grad = cfg[:9]
         lib = L.load()
         dt = compute_dtype()
         x = canon(x)
