@@ -405,13 +405,17 @@ int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s
 template <bool BF16>
 static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
+  // MT_IGEMM_FORCE (diagnostics, tools/layer_table.py): 1 = 2-stage kernel only, 2 = 4-wave ring variant wherever legal,
+  // 3 = 128x512 tiles wherever legal, 4 = 256x256 tiles wherever legal, 5 = 64-channel tiles for Cout % 128 == 0
+  static const int force = getenv("MT_IGEMM_FORCE") ? atoi(getenv("MT_IGEMM_FORCE")) : 0;
   int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
   // (the ping-pong kernel steps whole 4-chunk k-steps inside a tap and marks zero lanes with offsets >= 2 GiB)
   const bool pipe_ok = p.cpc % 4 == 0 && p.ph[0].ntaps <= 25 /* MT_PIPE_MAX_TAPS */ && p.x_bytes < 0x7f000000u &&
                        p.ph[0].w_bytes < 0x7f000000u;
   if (p.nphase == 1 && !p.raw && p.CoRows % 256 == 0 && pipe_ok) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
-    if (n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) { PT = 256; WT = 256; }
+    if ((n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) || force == 4) { PT = 256; WT = 256; }
+    if (force == 1 || force == 2 || force == 3) { PT = 128; WT = 128; }
   }
   // 128 couts x 512 pixels ping-pong tiles for the Cout = 128 layers (any number of phases, <= 9 taps each)
   if (WT == 128 && PT == 128 && !p.raw && p.stats == nullptr && p.CoRows % 128 == 0 && p.cpc % 4 == 0 &&
@@ -422,14 +426,15 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
       ok = ok && p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
       n512 += cdiv(p.ph[i].M, 512) * (p.CoRows / 128);
     }
-    if (ok && n512 >= 224 && (n512 % 256 == 0 || n512 >= 768)) { PT = 512; WT = 128; }
+    if (ok && ((n512 >= 224 && (n512 % 256 == 0 || n512 >= 768)) || force == 3)) { PT = 512; WT = 128; }
+    if (force == 1 || force == 2) { PT = 128; WT = 128; }
   }
   // latency-bound small launches (e.g. the ring GEMM of the stride-1 data gradient, 68 blocks): 64-channel tiles
   // double the number of blocks that share the serial k loop (-0.3 ms per step)
   if (WT == 128 && PT == 128 && !p.raw && p.CoRows % 128 == 0) {
     int t128 = 0;
     for (int i = 0; i < p.nphase; i++) t128 += cdiv(p.ph[i].M, PT) * cdiv(p.CoRows, 128);
-    if (t128 <= 128) WT = 64;
+    if (t128 <= 128 || force == 5) WT = 64;
   }
   int total = 0;
   for (int i = 0; i < p.nphase; i++) {
@@ -448,7 +453,8 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
   if (PT >= 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   // launches that do not fill the chip (latency-bound k loops): the 4-wave ring variant
   {
-    bool ok = (WT == 128 || WT == 64) && !p.raw && p.cpc % 4 == 0 && p.x_bytes < 0x7f000000u && total <= 256;
+    bool ok = (WT == 128 || WT == 64) && !p.raw && p.cpc % 4 == 0 && p.x_bytes < 0x7f000000u &&
+              (total <= 256 || force == 2) && force != 1;
     for (int i = 0; i < p.nphase && ok; i++) ok = p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
     if (ok) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   }
