@@ -169,3 +169,46 @@ def test_inference_graph_matches_eager(tmp_path, hip_device):
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == (1, 3, 96, 160)
         assert torch.equal(a, b), f"graphed inference differs: max {(a - b).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("variant", ["ms_dis", "dis_content", "base_concat_dropout", "lsgan_sn"])
+def test_graph_mode_covers_the_optional_paths(variant, tmp_path, hip_device):
+    """The captured step with the optional flags that change the launch sequence: multi-scale discriminators, the
+    content discriminator's d_iter gating (two different graphs: full step / content-discriminator-only), BaseModel with
+    dropout (device-side Bernoulli masks), spectral norm (in-place power iteration inside the graph).  Losses stay finite
+    and follow the eager run of the same seed."""
+    from masterthesis_amd import models
+    from masterthesis_amd.dataset import SyntheticDataset
+    from masterthesis_amd.models.core import misc
+    kw = {"ms_dis": dict(ms_dis=True, ms_dim=4, crop_size=256, batch_size=1, num_domains=4),
+          "dis_content": dict(use_dis_content=True, crop_size=224, batch_size=1),
+          "base_concat_dropout": dict(concat=True, reparam=True, use_dropout=True),
+          "lsgan_sn": dict(gan_mode="lsgan", dis_sn=True)}[variant]
+    model_cls = models.BaseModel if variant.startswith("base") else models.AdaINModel
+    steps = 14 if variant == "dis_content" else 8
+    hist = {}
+    for graph in (False, True):
+        misc.set_random_source(None)
+        args = _args(str(tmp_path / str(graph)), graph, **kw)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        M = model_cls(args)
+        M.initialize()
+        ds = SyntheticDataset(args, length=2, seed=9)
+        items = [ds[i % 2] for i in range(args.batch_size)]
+        batch = {k: torch.stack([it[k] for it in items]).to(hip_device) for k in items[0]}
+        out = []
+        for it in range(steps):
+            M.update_lr()
+            M.set_inputs(batch)
+            M.optimize_parameters(it)
+            out.append(dict(M.sync_losses()))
+        hist[graph] = out
+        if graph:
+            n_graphs = sum("graph" in st for st in M._graphs.values())
+            assert n_graphs == (2 if variant == "dis_content" else 1), M._graphs.keys()
+    for it in range(steps):
+        for k, v in hist[True][it].items():
+            assert v == v and abs(v) < 1e6, f"{variant} iteration {it}: {k} = {v}"
+            e = hist[False][it][k]
+            assert abs(v - e) <= 2e-2 * abs(e) + 1e-3, f"{variant} iteration {it} loss {k}: graph {v} vs eager {e}"
