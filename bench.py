@@ -190,6 +190,7 @@ def main():
         raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {o.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    local = local % torch.cuda.device_count()       # (MT_DIST_BACKEND=gloo rehearsals: several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

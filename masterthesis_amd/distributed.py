@@ -21,9 +21,11 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # "nccl" is RCCL on ROCm.  MT_DIST_BACKEND=gloo: host-staged collectives on device tensors -- lets several
+            # ranks share ONE GPU, which RCCL refuses (rehearsal of the N > 1 path on a single-GPU box)
+            backend = os.environ.get("MT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
