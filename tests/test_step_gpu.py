@@ -196,6 +196,18 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
         misc.set_random_source(None)
 
 
+@pytest.mark.parametrize("name", ["adain_step_d2", "adain_step_ms"])
+def test_training_step_matches_reference_in_deterministic_mode(name, tmp_path, hip_device):
+    """The same parity bounds with every reduction in fixed order (MT_DETERMINISTIC: the convolutions' fused statistics
+    epilogue -- the last user of float atomics -- is replaced by the separate two-stage statistics pass)."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_deterministic(True)
+    try:
+        test_training_step_matches_reference(name, "fp32", tmp_path, hip_device)
+    finally:
+        ops.set_deterministic(False)
+
+
 def test_generator_outputs_within_1e3_of_reference(tmp_path, hip_device):
     """north_star: generator outputs within 1e-3 rel of the CPU reference (fp32 path)."""
     from masterthesis_amd import hip_ops as ops
