@@ -128,6 +128,13 @@ int mt_norm_finalize(int mode, const float* sums, const float* gb, const float* 
 int mt_scale_shift_act(int dtype, const void* x, const float* scale, const float* shift,
                        const void* res, void* y, int N, int HW, int Cp, int act, float slope,
                        mt_stream_t s);
+/* mt_norm_finalize + mt_scale_shift_act in ONE launch for complete per-image statistics (sums [N][Cp][2]: the stats of
+ * mt_conv_fwd_stats, or an mt_nc_stats result with nparts == 1): every block derives the coefficients of its image once
+ * and streams its pixels.  mode INSTANCE / ADAIN / LAYER; coef [4][N][Cp] receives scale, shift, mean, rstd (what the
+ * backward calls take).  "conv -> norm -> activation (+ residual)" is then two launches: conv(+statistics), this. */
+int mt_norm_apply_fused(int dtype, int mode, const void* x, const float* sums, const float* gb, const float* gamma,
+                        const float* beta, const void* res, void* y, float* coef, int N, int HW, int C, int Cp, int act,
+                        float slope, float eps, mt_stream_t s);
 /* g = dy * act'(scale*x+shift); part2[n][k][c] = {sum g, sum g*x} over pixel block k (layout and nparts as
  * mt_nc_stats). */
 int mt_nc_stats_bwd(int dtype, const void* dy, const void* x, const float* scale,

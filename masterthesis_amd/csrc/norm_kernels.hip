@@ -358,6 +358,134 @@ extern "C" int mt_scale_shift_act(int dtype, const void* x, const float* scale, 
   return 0;
 }
 
+// Finalize + apply in ONE kernel for statistics that are already complete per image (sums [N][Cp][2], e.g. from the
+// convolution's epilogue): every block derives the scale / shift of ITS image once (one thread per channel, through
+// LDS), then streams its pixels.  InstanceNorm / AdaIN / LayerNorm + activation (+ residual) after a convolution is
+// then conv(+statistics) -> this kernel.  Block (0, n) also stores scale, shift, mean, rstd for the backward pass.
+// (Round 1 derived the coefficients per THREAD -- 8 channels for 64 elements of work -- and lost 1 ms per step; per
+// block it is 256 channel finalizations for 16 k elements.)
+template <bool BF16>
+__global__ __launch_bounds__(256) void norm_apply_fused_kernel(const u32x4* __restrict__ x, const float* __restrict__ sums,
+                                                               const float* __restrict__ gb, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const u32x4* __restrict__ res,
+                                                               u32x4* __restrict__ y, float* __restrict__ coef, int N, int HW,
+                                                               int C, int cchunks, int pix_per_block, int mode, int act,
+                                                               float slope, float eps) {
+  constexpr int V = Elem<BF16>::V;
+  __shared__ float s_sc[MT_FIN_MAXC], s_sh[MT_FIN_MAXC];
+  __shared__ float redw[2][4];
+  __shared__ float bc[2];
+  const int n = blockIdx.y;
+  const int Cp = cchunks * V;
+  const float2* sn = (const float2*)sums + (long)n * Cp;
+  float lmean = 0.f, lrstd = 0.f;
+  if (mode == MT_NORM_LAYER) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { const float2 v = sn[c]; a += v.x; b += v.y; }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { redw[0][threadIdx.x >> 6] = a; redw[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ta = 0.f, tb = 0.f;
+      for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) { ta += redw[0][w]; tb += redw[1][w]; }
+      const float cnt = (float)C * (float)HW;
+      const float m = ta / cnt;
+      float var = tb / cnt - m * m;
+      var = var > 0.f ? var : 0.f;
+      bc[0] = m; bc[1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    lmean = bc[0]; lrstd = bc[1];
+  }
+  const bool keeper = blockIdx.x == 0;
+  const long NC = (long)N * Cp;
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    float m = 0.f, r = 0.f, sc = 0.f, sh = 0.f;
+    if (c < C) {
+      if (mode == MT_NORM_LAYER) {
+        m = lmean; r = lrstd;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        sc = r * g; sh = b - m * r * g;
+      } else {
+        const float2 v = sn[c];
+        m = v.x / (float)HW;
+        float var = v.y / (float)HW - m * m;
+        var = var > 0.f ? var : 0.f;
+        r = rsqrtf(var + eps);
+        float a = 1.f, b = 0.f;
+        if (mode == MT_NORM_ADAIN) { a = 1.f + gb[(long)n * 2 * C + c]; b = gb[(long)n * 2 * C + C + c]; }
+        sc = r * a; sh = b - m * r * a;
+      }
+    }
+    s_sc[c] = sc; s_sh[c] = sh;
+    if (keeper) {
+      const long i = (long)n * Cp + c;
+      coef[i] = sc; coef[NC + i] = sh; coef[2 * NC + i] = m; coef[3 * NC + i] = r;
+    }
+  }
+  __syncthreads();
+  const int cq = threadIdx.x % cchunks;
+  const int pl = threadIdx.x / cchunks;
+  const int npl = blockDim.x / cchunks;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float sc[V], sh[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) { sc[e] = s_sc[cq * V + e]; sh[e] = s_sh[cq * V + e]; }
+  const long base = (long)n * HW * cchunks + cq;
+  auto one = [&](long i, const u32x4& xv, const u32x4& rv) {
+    float f[V], r[V];
+    Elem<BF16>::unpack(xv, f);
+    if (res) Elem<BF16>::unpack(rv, r);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      float v = act_apply(sc[e] * f[e] + sh[e], act, slope);
+      if (res) v += r[e];
+      f[e] = v;
+    }
+    __builtin_nontemporal_store(Elem<BF16>::pack(f), &y[i]);
+  };
+  constexpr int U = 4;
+  int px = p0 + pl;
+  for (; px + (U - 1) * npl < p1; px += U * npl) {
+    u32x4 xv[U], rv[U];
+    long idx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      idx[u] = base + (long)(px + u * npl) * cchunks;
+      xv[u] = x[idx[u]];
+      rv[u] = res ? res[idx[u]] : xv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) one(idx[u], xv[u], rv[u]);
+  }
+  for (; px < p1; px += npl) {
+    const long i = base + (long)px * cchunks;
+    const u32x4 xv = x[i];
+    one(i, xv, res ? res[i] : xv);
+  }
+}
+extern "C" int mt_norm_apply_fused(int dtype, int mode, const void* x, const float* sums, const float* gb,
+                                   const float* gamma, const float* beta, const void* res, void* y, float* coef, int N,
+                                   int HW, int C, int Cp, int act, float slope, float eps, mt_stream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  const int cchunks = Cp / V;
+  MT_CHECK(cchunks >= 1 && cchunks <= 256 && Cp <= MT_FIN_MAXC, "norm_apply_fused: unsupported channel count %d", Cp);
+  MT_CHECK(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN || mode == MT_NORM_LAYER, "norm_apply_fused: bad mode %d", mode);
+  MT_CHECK(mode != MT_NORM_ADAIN || gb != nullptr, "norm_apply_fused: adain needs gb");
+  MT_CHECK(sums != nullptr && coef != nullptr, "norm_apply_fused: null sums / coef");
+  if ((long)N * HW == 0) return 0;
+  int threads, ppb;
+  dim3 grid;
+  ew_geometry(HW, cchunks, N, &threads, &ppb, &grid);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((norm_apply_fused_kernel<true>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)x, sums, gb, gamma, beta, (const u32x4*)res, (u32x4*)y, coef, N, HW, C, cchunks, ppb, mode, act, slope, eps);
+  else
+    hipLaunchKernelGGL((norm_apply_fused_kernel<false>), grid, dim3(threads), 0, (hipStream_t)s, (const u32x4*)x, sums, gb, gamma, beta, (const u32x4*)res, (u32x4*)y, coef, N, HW, C, cchunks, ppb, mode, act, slope, eps);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // Backward coefficients.  With xh = (x-m)*r, a = per-(n,c) multiplier of xh in the forward
 // (1, 1+gamma_adain or gamma_layer), S1 = sum g, S2 = sum g*x over the pixels:
 //   sum g*xh = r*(S2 - m*S1)

@@ -656,19 +656,24 @@ class _Norm(torch.autograd.Function):
         bt = None if beta is None else _f32c(beta.detach())
         if gbc is not None and tuple(gbc.shape) != (N, 2 * Cc):
             raise RuntimeError(f"adain: expected style projection of shape {(N, 2 * Cc)}, got {tuple(gbc.shape)}")
-        if mode == L.NORM_BATCH:
-            rm, rv, momentum, training = bn
-            L.check(lib.mt_bn_finalize(_ptr(sums), _ptr(gm), _ptr(bt), _ptr(rm), _ptr(rv), float(momentum), eps,
-                                       int(training), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc,
-                                       Cp, nparts, _stream()), "mt_bn_finalize")
-        else:
-            L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
-                                         _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, nparts, _stream()),
-                    "mt_norm_finalize")
         r = None if res is None else canon(res)
         y = new_act(N, Cc, H, W, x.dtype, dev)
-        L.check(lib.mt_scale_shift_act(mt, _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(r), _ptr(y), N, HW, Cp, act,
-                                       slope, _stream()), "mt_scale_shift_act")
+        if mode != L.NORM_BATCH and sums is not None and nparts == 1 and Cp <= 2048:
+            # complete per-image statistics (the convolution's epilogue produced them): finalize + apply in ONE launch
+            L.check(lib.mt_norm_apply_fused(mt, mode, _ptr(x), _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(r), _ptr(y),
+                                            _ptr(coef), N, HW, Cc, Cp, act, slope, eps, _stream()), "mt_norm_apply_fused")
+        else:
+            if mode == L.NORM_BATCH:
+                rm, rv, momentum, training = bn
+                L.check(lib.mt_bn_finalize(_ptr(sums), _ptr(gm), _ptr(bt), _ptr(rm), _ptr(rv), float(momentum), eps,
+                                           int(training), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]), N, HW,
+                                           Cc, Cp, nparts, _stream()), "mt_bn_finalize")
+            else:
+                L.check(lib.mt_norm_finalize(mode, _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(coef[0]), _ptr(coef[1]),
+                                             _ptr(coef[2]), _ptr(coef[3]), N, HW, Cc, Cp, eps, nparts, _stream()),
+                        "mt_norm_finalize")
+            L.check(lib.mt_scale_shift_act(mt, _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(r), _ptr(y), N, HW, Cp, act,
+                                           slope, _stream()), "mt_scale_shift_act")
         ctx.cfg = cfg
         ctx.save_for_backward(x, coef, gbc, gm)
         ctx.shapes = (None if gamma is None else gamma.shape, None if beta is None else beta.shape)
