@@ -94,10 +94,13 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     # (cosine lower bound, norm-ratio window) per optimizer step of iteration 0
     # measured over the 16 fixtures (bf16): D phases cos 0.931-1.000 / ratio 0.93-1.08, phase 3 cos 0.850-1.000 /
     # ratio 0.96-1.15.  Phase 4 is the small residual of cancelling terms at these widths (the normalisation backward
-    # subtracts the mean of an almost uniform gradient; fp32 itself is 3-8 % off): bf16 keeps the direction (cos
-    # 0.27-0.99) but not the norm (ratio 0.15-1.2, every decoder tensor shrinks alike -- per-tensor table under
-    # MT_STEP_DIAG=2), so only a gross bound there; the fp32 run of the same fixture pins the logic to 1e-6.
-    dir_tol = [(0.9, (0.85, 1.15))] * 2 + [(0.8, (0.9, 1.25))] * 3 + [(0.2, (0.1, 3.0))] * 2
+    # subtracts the mean of an almost uniform gradient; fp32 itself is 3-8 % off): in bf16 neither the norm (ratio
+    # 0.15-1.2, every decoder tensor shrinks alike -- per-tensor table under MT_STEP_DIAG=2) nor even the direction is
+    # stable: the `nearest` fixture's decoder gradient came out at cos +0.79, +0.79 and -0.90 in three consecutive runs of
+    # the same binary (the order of the fp32 atomics in the fused statistics epilogue decides which side of a ReLU a
+    # handful of activations land on).  So phase 4 only gets a gross norm window in bf16; the fp32 run of the same fixture
+    # pins the logic to 1e-6, and at real widths bf16 tracks fp32 (tests/test_fullsize_gpu.py).
+    dir_tol = [(0.9, (0.85, 1.15))] * 2 + [(0.8, (0.9, 1.25))] * 3 + [(-1.0, (0.1, 3.0))] * 2
     # --dis_sn at these widths: with spectrally normalised weights the adversarial term dominates the generator
     # gradient, and d(logit)/d(image) is piecewise constant in the LeakyReLU pattern of a 4-channel discriminator.
     # Measured on the fp64 oracle: a 1e-7 relative perturbation of the input images moves the phase-3 gradient by
