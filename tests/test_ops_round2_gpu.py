@@ -1,0 +1,178 @@
+"""Op-level GPU tests of the C-ABI entry points added in round 2, each against plain torch on the CPU (or against
+the two-launch path it replaces): one-launch loss expression, device-record Adam, device-state Philox draws, the
+two-stage reproducible statistics, finalize+apply in one launch, activation-derivative + bias gradient in one pass."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from masterthesis_amd import _lib as L
+    return L, L.load()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_loss_sum_matches_torch_expression(hip_device):
+    from masterthesis_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(0)
+    vals = torch.randn(7, generator=g)
+    ts = [v.clone().to(hip_device).requires_grad_() for v in vals]
+    groups = [("adv", [(ts[0], 1.0), (ts[1], 1.0), (ts[2], 0.5)], 1.0, 1.0),
+              ("cls", [(ts[3], 5.0)], 2.0, 2.0),
+              ("rec", [(ts[4], 10.0), (ts[5], 10.0)], 1.0, 1.0),
+              ("kl", [(ts[6], 0.01)], 8.0, 1.0)]          # differentiated with weight 8 (world size), reported with 1
+    total, v, reported = ops.loss_sum(groups)
+    (total * 3.0).backward()
+    ref = [t.detach().cpu().double().requires_grad_() for t in ts]
+    adv = ref[0] + ref[1] + 0.5 * ref[2]
+    cls, rec, kl = 5.0 * ref[3], 10.0 * ref[4] + 10.0 * ref[5], 0.01 * ref[6]
+    want_total = adv + 2.0 * cls + rec + 8.0 * kl
+    (want_total * 3.0).backward()
+    assert abs(total.item() - want_total.item()) < 1e-5 * max(1.0, abs(want_total.item()))
+    assert abs(reported.item() - (adv + 2.0 * cls + rec + kl).item()) < 1e-5 * max(1.0, abs(want_total.item()))
+    for name, want in (("adv", adv), ("cls", cls), ("rec", rec), ("kl", kl)):
+        assert abs(v[name].item() - want.item()) < 1e-5 * max(1.0, abs(want.item())), name
+    for a, b in zip(ts, ref):
+        assert abs(a.grad.item() - b.grad.item()) < 1e-6 * max(1.0, abs(b.grad.item()))
+
+
+def test_fused_adam_device_record_matches_torch_adam(hip_device):
+    """FusedAdam (step count / bias corrections / lr in a device record, gradients cleared by the update) against
+    torch.optim.Adam on the CPU over several steps, with a learning-rate change in between."""
+    from masterthesis_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(7, 5, 3, 3), (7,), (11, 13)]
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in p0]
+    dev_p = [torch.nn.Parameter(p.clone().to(hip_device)) for p in p0]
+    ref = torch.optim.Adam(ref_p, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    opt = FusedAdam(dev_p, lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-4)
+    for it in range(6):
+        if it == 3:
+            for o in (ref, opt):
+                o.param_groups[0]["lr"] = 2.5e-4
+        opt.zero_grad()
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for rp, dp, gr in zip(ref_p, dev_p, grads):
+            rp.grad = gr.clone()
+            dp.grad.copy_(gr.to(hip_device))
+        ref.step()
+        opt.step()
+        assert float(opt.flat_grad().abs().max()) == 0.0, "the update must clear the gradients it consumed"
+    for rp, dp in zip(ref_p, dev_p):
+        err = (dp.detach().cpu() - rp.detach()).abs().max().item()
+        assert err < 2e-6, err
+    assert int(opt._dev.view(torch.int32)[1].item()) == 6 == opt._step_count_mt
+
+
+def test_device_state_noise_is_standard_normal_and_advances(hip_device):
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.float32)
+    st = torch.tensor([12345, 0], dtype=torch.int64).to(hip_device)
+    x = ops.canon(torch.zeros(2, 64, 64, 64, device=hip_device))
+    a = ops.gaussian_noise_add_dev(x, st)
+    b = ops.gaussian_noise_add_dev(x, st)
+    assert st.tolist() == [12345, 2]
+    fa, fb = ops.to_nchw_f32(a).flatten(), ops.to_nchw_f32(b).flatten()
+    assert abs(fa.mean().item()) < 5e-3 and abs(fa.std().item() - 1.0) < 5e-3
+    assert (fa - fb).abs().max().item() > 1.0, "consecutive draws must differ"
+    # the same (seed, counter) reproduces the draw
+    st2 = torch.tensor([12345, 0], dtype=torch.int64).to(hip_device)
+    assert torch.equal(ops.to_nchw_f32(ops.gaussian_noise_add_dev(x, st2)).flatten(), fa)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 8, 5, 7), (2, 24, 33, 17), (2, 256, 16, 16), (1, 520, 6, 6), (4, 64, 64, 64)])
+def test_two_stage_statistics_are_exact_and_reproducible(shape, dtype, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    L, lib = _lib()
+    ops.set_compute_dtype(dtype)
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.randn(shape, generator=g)
+    x = ops.canon(x0.to(hip_device))
+    xr = ops.to_nchw_f32(x).cpu().double()              # (what the kernel actually sees after bf16 rounding)
+    Cp, HW = ops.padc(Cc), H * W
+    mt = L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
+    nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
+    assert 1 <= nparts <= 64
+    outs = []
+    for _ in range(2):
+        part = torch.full((N, nparts, Cp, 2), float("nan"), dtype=torch.float32, device=hip_device)
+        L.check(lib.mt_nc_stats(mt, P(x), P(part), N, HW, Cp, S()), "mt_nc_stats")
+        outs.append(part.clone())
+    assert torch.equal(outs[0], outs[1]), "statistics differ between two identical launches"
+    tot = outs[0].double().sum(1).cpu()
+    assert torch.isfinite(tot).all()
+    s1, s2 = xr.sum((2, 3)), (xr * xr).sum((2, 3))
+    assert (tot[:, :Cc, 0] - s1).abs().max().item() <= 1e-4 * (s1.abs().max().item() + 1.0)
+    assert (tot[:, :Cc, 1] - s2).abs().max().item() <= 1e-4 * s2.abs().max().item()
+    assert float(tot[:, Cc:].abs().max()) == 0.0 if Cp > Cc else True
+
+
+@pytest.mark.parametrize("mode_name", ["instance", "adain", "layer"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_norm_apply_fused_equals_finalize_plus_apply(mode_name, dtype, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    L, lib = _lib()
+    ops.set_compute_dtype(dtype)
+    mode = {"instance": L.NORM_INSTANCE, "adain": L.NORM_ADAIN, "layer": L.NORM_LAYER}[mode_name]
+    N, Cc, H, W = 3, 20, 9, 11
+    g = torch.Generator().manual_seed(7)
+    x = ops.canon(torch.randn(N, Cc, H, W, generator=g).to(hip_device))
+    res = ops.canon(torch.randn(N, Cc, H, W, generator=g).to(hip_device))
+    gb = torch.randn(N, 2 * Cc, generator=g).to(hip_device) if mode == L.NORM_ADAIN else None
+    gamma = torch.randn(Cc, generator=g).to(hip_device) if mode == L.NORM_LAYER else None
+    beta = torch.randn(Cc, generator=g).to(hip_device) if mode == L.NORM_LAYER else None
+    Cp, HW = ops.padc(Cc), H * W
+    mt = L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
+    # complete per-image sums [N][Cp][2] (what the convolution's epilogue hands over)
+    xr = ops.to_nchw_f32(x)
+    sums = torch.zeros(N, Cp, 2, device=hip_device)
+    sums[:, :Cc, 0], sums[:, :Cc, 1] = xr.sum((2, 3)), (xr * xr).sum((2, 3))
+    coef_a = torch.empty(4, N, Cp, device=hip_device)
+    ya = ops.new_act(N, Cc, H, W, x.dtype, hip_device)
+    L.check(lib.mt_norm_finalize(mode, P(sums), P(gb), P(gamma), P(beta), P(coef_a[0]), P(coef_a[1]), P(coef_a[2]), P(coef_a[3]),
+                                 N, HW, Cc, Cp, 1e-5, 1, S()), "mt_norm_finalize")
+    L.check(lib.mt_scale_shift_act(mt, P(x), P(coef_a[0]), P(coef_a[1]), P(res), P(ya), N, HW, Cp, L.ACT_RELU, 0.01, S()),
+            "mt_scale_shift_act")
+    coef_b = torch.full((4, N, Cp), float("nan"), device=hip_device)
+    yb = ops.new_act(N, Cc, H, W, x.dtype, hip_device)
+    L.check(lib.mt_norm_apply_fused(mt, mode, P(x), P(sums), P(gb), P(gamma), P(beta), P(res), P(yb), P(coef_b), N, HW, Cc, Cp,
+                                    L.ACT_RELU, 0.01, 1e-5, S()), "mt_norm_apply_fused")
+    assert torch.equal(coef_a, coef_b)
+    assert torch.equal(ops.to_nchw_f32(ya), ops.to_nchw_f32(yb))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_act_bwd_bias_equals_act_bwd_then_column_sum(dtype, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    L, lib = _lib()
+    ops.set_compute_dtype(dtype)
+    N, Cc, H, W = 2, 20, 13, 9
+    g = torch.Generator().manual_seed(3)
+    dy = ops.canon(torch.randn(N, Cc, H, W, generator=g).to(hip_device))
+    y = ops.canon(torch.randn(N, Cc, H, W, generator=g).to(hip_device))
+    Cp, npix = ops.padc(Cc), N * H * W
+    mt = L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
+    dz_a = ops.new_act(N, Cc, H, W, dy.dtype, hip_device, zero=True)
+    L.check(lib.mt_act_bwd(mt, P(dy), P(y), P(dz_a), npix * Cp, L.ACT_LRELU, 0.01, S()), "mt_act_bwd")
+    nws = int(lib.mt_act_bwd_bias_ws_bytes(Cp))
+    ws = torch.empty(nws, dtype=torch.uint8, device=hip_device)
+    dz_b = ops.new_act(N, Cc, H, W, dy.dtype, hip_device, zero=True)
+    db = torch.full((Cc,), 2.0, device=hip_device)                       # accumulate onto existing contents
+    L.check(lib.mt_act_bwd_bias(mt, P(dy), P(y), P(dz_b), npix, Cp, Cc, L.ACT_LRELU, 0.01, P(db), 1, P(ws), nws, S()),
+            "mt_act_bwd_bias")
+    assert torch.equal(ops.to_nchw_f32(dz_a), ops.to_nchw_f32(dz_b))
+    want = ops.to_nchw_f32(dz_a).double().sum((0, 2, 3)) + 2.0
+    assert (db.double() - want).abs().max().item() < 1e-4 * (want.abs().max().item() + 1.0)
