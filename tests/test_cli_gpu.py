@@ -197,3 +197,27 @@ def test_rccl_exchange_path_single_rank(comm, tmp_path, hip_device, monkeypatch)
     for la, lb in zip(a, b):
         for k in la:
             assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+
+
+def test_train_cli_hip_graph_with_checkpoints(tmp_path, hip_device):
+    """--hip_graph through the command line: 9 iterations (3 eager, 1 capturing, 5 replayed) with logging / saving /
+    image dumps in between; the optimizer checkpoint written after replays carries the right Adam step count, and a run
+    resumed from it continues."""
+    from masterthesis_amd import train
+    from masterthesis_amd.models.core import misc
+    misc.set_random_source(None)
+    common = ["--model", "AdaINModel", "--dataset", "SyntheticDataset", "--exp_dir", str(tmp_path), "--name", "run",
+              "--batch_size", "2", "--num_domains", "2", "--dim", "8", "--crop_size", "64", "--num_workers", "0",
+              "--synthetic_len", "4", "--print_freq", "2", "--save_freq", "4", "--display_freq", "3", "--precision", "bf16",
+              "--hip_graph"]
+    train.main(common + ["--n_iters", "8", "--max_iter", "8"])
+    ck = os.path.join(str(tmp_path), "run", "checkpoints")
+    assert {"model_0.ckpt", "model_4.ckpt", "model_8.ckpt", "model_9.ckpt"} <= set(os.listdir(ck))
+    opt = torch.load(os.path.join(ck, "opt_9.ckpt"))
+    assert all(int(s["step"]) == 18 for s in opt["decoder"]["state"].values())      # 9 iterations x 2 decoder steps
+    assert all(int(s["step"]) == 9 for s in opt["discriminator2"]["state"].values())
+    sd = torch.load(os.path.join(ck, "model_9.ckpt"))
+    assert all(torch.isfinite(v).all() for net in sd.values() for v in net.values())
+    train.main(common + ["--n_iters", "12", "--max_iter", "12", "--resume", os.path.join(ck, "model_9.ckpt"),
+                         "--resume_opt", os.path.join(ck, "opt_9.ckpt"), "--last_iter", "9"])
+    assert "model_13.ckpt" in os.listdir(ck)
