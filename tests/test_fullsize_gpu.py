@@ -152,9 +152,22 @@ def test_full_size_step_runs_and_is_finite(cfg, tmp_path, hip_device):
         assert (after - before[n]).abs().max().item() > 0, f"{n} did not move"
 
 
-def test_short_training_run_bf16_tracks_fp32(tmp_path, hip_device):
+@pytest.mark.parametrize("deterministic", [False, True], ids=["atomics", "deterministic"])
+def test_short_training_run_bf16_tracks_fp32(deterministic, tmp_path, hip_device):
     """80 optimisation steps (128x128, 4 pairs, dim 64) in bf16 and in fp32 from the same seed: the reconstruction
-    losses must go down and the bf16 trajectory must stay within a few percent of the fp32 one."""
+    losses must go down and the bf16 trajectory must stay within a few percent of the fp32 one.  In deterministic mode
+    (fixed-order reductions: the run is bit-reproducible) the discriminator loss is pinned too."""
+    from masterthesis_amd import hip_ops as _ops
+    from masterthesis_amd.models.core import misc as _misc
+    _ops.set_deterministic(deterministic)
+    _misc.set_random_source(None)
+    try:
+        _short_training_run(deterministic, tmp_path, hip_device)
+    finally:
+        _ops.set_deterministic(False)
+
+
+def _short_training_run(deterministic, tmp_path, hip_device):
     import argparse
     import os
     import sys
@@ -195,6 +208,12 @@ def test_short_training_run_bf16_tracks_fp32(tmp_path, hip_device):
     for prec in ("bf16", "fp32"):
         d = out[prec][1]["d_total"]
         assert 0.3 < d < 2.5, f"{prec}: d_total {d} after 80 steps"
+    print(f"MT_DIAG short run deterministic={deterministic}: " +
+          ", ".join(f"{p} d_total {out[p][1]['d_total']:.4f} total_g {out[p][1]['total_g']:.4f}" for p in ("bf16", "fp32")))
+    if deterministic:
+        # no run-to-run scatter left: what remains is the precision difference itself
+        a, b = out["bf16"][1]["d_total"], out["fp32"][1]["d_total"]
+        assert abs(a - b) <= 0.25 * abs(b), f"d_total: bf16 {a} vs fp32 {b} after 80 deterministic steps"
 
 
 def test_sampling_path_at_deployment_size(hip_device):
