@@ -111,6 +111,15 @@ int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int 
 int mt_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
                   float* db, int n, int in, int out, int accumulate, mt_stream_t s);
 
+/* G <= 8 nn.Linear layers of equal shape that share their input x [n][in] (the four AdaIN projections of a decoder, all
+ * applied to the same style code: norm.py:27, blocks.py:152-164) in one launch: y_g = x w_g^T + b_g.  w, b, y: HOST arrays
+ * of G device pointers (b may be NULL, or hold NULLs).  Backward: dx = sum_g dy_g w_g (groups added in index order; may
+ * be NULL), dw_g / db_g as mt_linear_bwd (entries may be NULL), accumulate as there. */
+int mt_linear_group_fwd(const float* x, const float* const* w, const float* const* b, float* const* y, int groups, int n,
+                        int in, int out, mt_stream_t s);
+int mt_linear_group_bwd(const float* x, const float* const* w, const float* const* dy, float* dx, float* const* dw,
+                        float* const* db, int groups, int n, int in, int out, int accumulate, mt_stream_t s);
+
 /* ---- normalisation family (K9, K10, K11): functions.py:17, norm.py:5-33 -------------- */
 /* Statistics pass: part[n][k][c] = {sum x, sum x^2} over the k-th pixel block of image n (fp32,
  * [N][nparts][Cp][2], nparts = mt_nc_stats_parts(dtype, N, HW, Cp) <= 64; every element is written, nothing to

@@ -110,6 +110,8 @@ SIGNATURES = {
     "mt_adam_multi_dev": (_i, [_p, _p, _i, _i64, _f, _f, _f, _f, _p, _i, _p]),
     "mt_loss_sum_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p]),
     "mt_loss_sum_bwd": (_i, [_p, _p, _p, _i, _p, _i, _p, _p]),
+    "mt_linear_group_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_linear_group_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mt_comm_unique_id": (_i, [_p]),
     "mt_comm_init": (_i, [C.POINTER(_p), _i, _i, _p, _i]),
     "mt_comm_allreduce_async": (_i, [_p, _p, _z, _p]),

@@ -83,6 +83,105 @@ extern "C" int mt_linear_bwd(const float* x, const float* w, const float* dy, fl
   return 0;
 }
 
+// ---- grouped Linear: G layers that share their input (the four AdaIN projections of a decoder, norm.py:27 /
+// blocks.py:152-164: four launches forward, eight plus three gradient sums backward) in ONE launch each way -------------
+#define MT_LINEAR_MAX_GROUPS 8
+struct LinearGroupArgs {
+  const float* w[MT_LINEAR_MAX_GROUPS];
+  const float* b[MT_LINEAR_MAX_GROUPS];
+  const float* dy[MT_LINEAR_MAX_GROUPS];
+  float* y[MT_LINEAR_MAX_GROUPS];
+  float* dw[MT_LINEAR_MAX_GROUPS];
+  float* db[MT_LINEAR_MAX_GROUPS];
+  int groups;
+};
+__global__ void linear_group_fwd_kernel(const float* __restrict__ x, LinearGroupArgs a, int n, int in, int out) {
+  const int g = blockIdx.y;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * out) return;
+  const int r = wave / out, o = wave % out;
+  const float* __restrict__ w = a.w[g];
+  float acc = 0.f;
+  for (int i = lane; i < in; i += 64) acc += x[(long)r * in + i] * w[(long)o * in + i];
+  acc = wave_sum(acc);
+  if (lane == 0) a.y[g][wave] = acc + (a.b[g] ? a.b[g][o] : 0.f);
+}
+// dx[n][i] = sum_g sum_o dy_g[n][o] w_g[o][i]   (groups added in index order)
+__global__ __launch_bounds__(256) void linear_group_bwd_dx_kernel(LinearGroupArgs a, float* __restrict__ dx, int n, int in,
+                                                                  int out) {
+  __shared__ float red[256];
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (i < in) {
+    for (int g = 0; g < a.groups; g++) {
+      const float* __restrict__ w = a.w[g];
+      const float* __restrict__ dy = a.dy[g];
+#pragma unroll 8
+      for (int o = sl; o < out; o += 4) acc += dy[(long)r * out + o] * w[(long)o * in + i];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && i < in) dx[(long)r * in + i] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+}
+__global__ void linear_group_bwd_dw_kernel(const float* __restrict__ x, LinearGroupArgs a, int n, int in, int out,
+                                           int accumulate) {
+  const int g = blockIdx.y;
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)out * in) return;
+  const int o = (int)(idx / in), i = (int)(idx % in);
+  const float* __restrict__ dy = a.dy[g];
+  float acc = 0.f, bsum = 0.f;
+  for (int r = 0; r < n; r++) {
+    const float gv = dy[(long)r * out + o];
+    acc += gv * x[(long)r * in + i];
+    bsum += gv;
+  }
+  float* dw = a.dw[g];
+  float* db = a.db[g];
+  if (dw) dw[idx] = accumulate ? dw[idx] + acc : acc;
+  if (db && i == 0) db[o] = accumulate ? db[o] + bsum : bsum;
+}
+extern "C" int mt_linear_group_fwd(const float* x, const float* const* w, const float* const* b, float* const* y,
+                                   int groups, int n, int in, int out, mt_stream_t s) {
+  MT_CHECK(groups >= 1 && groups <= MT_LINEAR_MAX_GROUPS, "linear_group: %d groups", groups);
+  if ((long)n * out == 0) return 0;
+  LinearGroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.groups = groups;
+  for (int g = 0; g < groups; g++) {
+    MT_CHECK(w[g] != nullptr && y[g] != nullptr, "linear_group_fwd: null weight / output %d", g);
+    a.w[g] = w[g]; a.b[g] = b ? b[g] : nullptr; a.y[g] = y[g];
+  }
+  hipLaunchKernelGGL(linear_group_fwd_kernel, dim3(cdiv((long)n * out, 4), groups), dim3(256), 0, (hipStream_t)s, x, a, n, in, out);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_linear_group_bwd(const float* x, const float* const* w, const float* const* dy, float* dx,
+                                   float* const* dw, float* const* db, int groups, int n, int in, int out,
+                                   int accumulate, mt_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  MT_CHECK(groups >= 1 && groups <= MT_LINEAR_MAX_GROUPS, "linear_group: %d groups", groups);
+  if (n == 0) return 0;
+  LinearGroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.groups = groups;
+  bool any_dw = false;
+  for (int g = 0; g < groups; g++) {
+    MT_CHECK(w[g] != nullptr && dy[g] != nullptr, "linear_group_bwd: null weight / gradient %d", g);
+    a.w[g] = w[g]; a.dy[g] = dy[g];
+    a.dw[g] = dw ? dw[g] : nullptr; a.db[g] = db ? db[g] : nullptr;
+    any_dw = any_dw || a.dw[g] || a.db[g];
+  }
+  if (dx) hipLaunchKernelGGL(linear_group_bwd_dx_kernel, dim3(cdiv(in, 64), n), dim3(256), 0, s, a, dx, n, in, out);
+  if (any_dw) hipLaunchKernelGGL(linear_group_bwd_dw_kernel, dim3(cdiv((long)out * in, 256), groups), dim3(256), 0, s, x, a, n, in, out, accumulate);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- fused multi-tensor Adam -----------------------------------------------------------------
 // grid = (chunks, tensors).  torch.optim.Adam semantics (no amsgrad, maximize=False):
 //   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;

@@ -627,6 +627,82 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias, torch.is_grad_enabled())
 
 
+class _LinearGroup(torch.autograd.Function):
+    """G nn.Linear layers of equal shape on ONE input in one launch (forward) / two launches (backward: dx summed over
+    the groups, dw / db per group) -- the four AdaIN projections of a decoder."""
+
+    @staticmethod
+    def forward(ctx, x, grad_on, *params):
+        G = len(params) // 2
+        ws, bs = params[:G], params[G:]
+        x = _f32c(x)
+        wd = [_f32c(w.detach()) for w in ws]
+        bd = [None if b is None else _f32c(b.detach()) for b in bs]
+        n, i = x.shape
+        o = wd[0].shape[0]
+        if any(tuple(w.shape) != (o, i) for w in wd):
+            raise RuntimeError("linear_grouped: all layers must share the shape [out, in] and match the input")
+        ys = [torch.empty((n, o), dtype=torch.float32, device=x.device) for _ in range(G)]
+        arr = lambda ts: (C.c_void_p * G)(*[None if t is None else t.data_ptr() for t in ts])   # noqa: E731
+        L.check(L.load().mt_linear_group_fwd(_ptr(x), arr(wd), arr(bd), arr(ys), G, n, i, o, _stream()),
+                "mt_linear_group_fwd")
+        ctx.save_for_backward(x, *wd)
+        ctx.G, ctx.owners_w, ctx.owners_b = G, ws, bs
+        ctx.counted_list = []
+        for w in ws:
+            cnt = bool(grad_on and w.requires_grad and w.is_leaf)
+            ctx.counted_list.append(cnt)
+            if cnt:
+                w._mt_pending = getattr(w, "_mt_pending", 0) + 1
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *wd = ctx.saved_tensors
+        G = ctx.G
+        n, i = x.shape
+        o = wd[0].shape[0]
+        dys = [torch.zeros((n, o), dtype=torch.float32, device=x.device) if d is None else _f32c(d) for d in dys]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = [ctx.needs_input_grad[2 + g] for g in range(G)]
+        need_b = [ctx.owners_b[g] is not None and ctx.needs_input_grad[2 + G + g] for g in range(G)]
+        gw = [_fused_grad_target(ctx.owners_w[g]) if need_w[g] else None for g in range(G)]
+        gb = [_fused_grad_target(ctx.owners_b[g]) if need_b[g] else None for g in range(G)]
+        fused = all((not need_w[g] or gw[g] is not None) and (not need_b[g] or gb[g] is not None) for g in range(G))
+        if fused:
+            dw, db = gw, gb
+        else:
+            dw = [torch.empty_like(wd[g]) if need_w[g] else None for g in range(G)]
+            db = [torch.empty((o,), dtype=torch.float32, device=x.device) if need_b[g] else None for g in range(G)]
+        arr = lambda ts: (C.c_void_p * G)(*[None if t is None else t.data_ptr() for t in ts])   # noqa: E731
+        L.check(L.load().mt_linear_group_bwd(_ptr(x), arr(wd), arr(dys), _ptr(dx), arr(dw), arr(db), G, n, i, o, int(fused),
+                                             _stream()), "mt_linear_group_bwd")
+        for g in range(G):
+            if ctx.counted_list[g]:
+                _grad_use_done(_UseToken(ctx.owners_w[g]))
+        if fused:
+            return (dx, None) + (None,) * (2 * G)
+        return (dx, None) + tuple(dw) + tuple(db)
+
+
+class _UseToken:
+    """adapter for _grad_use_done: one counted use of ``owner``"""
+    counted = True
+
+    def __init__(self, owner):
+        self.owner = owner
+
+
+def linear_grouped(x, layers):
+    """[nn.Linear-like (weight, bias), ...] of equal shape applied to the same input -> list of outputs, one launch."""
+    out = []
+    for k in range(0, len(layers), 8):              # (the launch carries up to 8 pointer sets)
+        ws = [w for w, _ in layers[k:k + 8]]
+        bs = [b for _, b in layers[k:k + 8]]
+        out += list(_LinearGroup.apply(x, torch.is_grad_enabled(), *ws, *bs))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # normalisation family
 # --------------------------------------------------------------------------------------

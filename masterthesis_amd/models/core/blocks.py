@@ -210,10 +210,12 @@ class AdaINResnetBlock(nn.Module):
         self.norm = AdaptiveInstanceNorm(output_dim, style_dim)
         self.dropout = Dropout(0.5) if dropout else nn.Identity()
 
-    def forward(self, x, z):
+    def forward(self, x, z, gb=None):
         # the reference evaluates norm.fc(z) at both norm sites (blocks.py:158-164): same weights, same input, so
-        # one projection serves both (its gradient is the sum of the two sites')
-        gb = self.norm.project(z)
+        # one projection serves both (its gradient is the sum of the two sites'); the decoder may hand in the
+        # projection it computed for all of its blocks in one launch
+        if gb is None:
+            gb = self.norm.project(z)
         y, sums = self.conv1(x, want_stats=True)
         h = self.norm(y, z, act=self.act, sums=sums, gb=gb)
         y, sums = self.conv2(h, want_stats=True)

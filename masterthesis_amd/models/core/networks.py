@@ -175,9 +175,11 @@ class AdaINDecoder(nn.Module):
 
     def forward(self, x, z, c):
         z_c = _run_mlp(self.linear, torch.cat([c, z], 1))      # class first (networks.py:264)
+        # every block projects the SAME style code with its own norm.fc (blocks.py:152): all projections in one launch
+        gbs = ops.linear_grouped(z_c, [(dec.norm.fc.weight, dec.norm.fc.bias) for dec in self.dec1])
         out = x
-        for dec in self.dec1:
-            out = dec(out, z_c)
+        for dec, gb in zip(self.dec1, gbs):
+            out = dec(out, z_c, gb=gb)
         for up in self.dec2:
             out = up(out)
         return out

@@ -176,3 +176,38 @@ def test_act_bwd_bias_equals_act_bwd_then_column_sum(dtype, hip_device):
     assert torch.equal(ops.to_nchw_f32(dz_a), ops.to_nchw_f32(dz_b))
     want = ops.to_nchw_f32(dz_a).double().sum((0, 2, 3)) + 2.0
     assert (db.double() - want).abs().max().item() < 1e-4 * (want.abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["autograd_grads", "accumulate_into_param_grad"])
+def test_linear_grouped_matches_separate_layers(fused, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    n, i, o, G = 5, 24, 40, 4
+    x0 = torch.randn(n, i, generator=g)
+    W = [torch.randn(o, i, generator=g) * 0.1 for _ in range(G)]
+    Bv = [torch.randn(o, generator=g) for _ in range(G)]
+    cot = [torch.randn(n, o, generator=g) for _ in range(G)]
+    xr = x0.clone().double().requires_grad_()
+    Wr = [w.clone().double().requires_grad_() for w in W]
+    Br = [b.clone().double().requires_grad_() for b in Bv]
+    sum(((xr @ Wr[k].t() + Br[k]) * cot[k].double()).sum() for k in range(G)).backward()
+    xd = x0.clone().to(hip_device).requires_grad_()
+    Wd = [torch.nn.Parameter(w.clone().to(hip_device)) for w in W]
+    Bd = [torch.nn.Parameter(b.clone().to(hip_device)) for b in Bv]
+    ops.set_fused_grad_accumulation(fused)
+    try:
+        if fused:
+            for p in Wd + Bd:
+                p.grad = torch.ones_like(p)             # the backward ADDS to what is there
+        ys = ops.linear_grouped(xd, list(zip(Wd, Bd)))
+        for k in range(G):
+            want = (x0 @ W[k].t() + Bv[k])
+            assert (ys[k].detach().cpu() - want).abs().max().item() < 1e-4
+        torch.autograd.backward(ys, [c.to(hip_device) for c in cot])
+    finally:
+        ops.set_fused_grad_accumulation(True)
+    off = 1.0 if fused else 0.0
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < 1e-4
+    for k in range(G):
+        assert (Wd[k].grad.cpu().double() - off - Wr[k].grad).abs().max().item() < 1e-4, k
+        assert (Bd[k].grad.cpu().double() - off - Br[k].grad).abs().max().item() < 1e-4, k
