@@ -115,7 +115,10 @@ class TranslationModel(Model):
     def _optimize_graphed(self, global_iter):
         kind = "dc" if (self.args.use_dis_content and global_iter % self.args.d_iter != 0) else "full"
         opts = list(self.optimizer.values())
-        key = (kind, tuple(o.generation for o in opts), ops.compute_dtype())
+        # (anything that changes the launch sequence invalidates the capture: rebuilt flat buffers, train / eval flags,
+        #  deterministic mode, the storage type)
+        key = (kind, tuple(o.generation for o in opts), ops.compute_dtype(), ops.deterministic(),
+               tuple(self.model[n].training for n in self.model))
         graphs = self.__dict__.setdefault("_graphs", {})
         st = graphs.setdefault(key, {"warm": 0})
         if st["warm"] < self.GRAPH_WARMUP:           # eager steps first: caches, flat buffers, pack tables, arenas settle
