@@ -15,7 +15,11 @@
  *    them into MFMA-friendly tiles with mt_conv_pack().
  *  - Ownership: the caller (PyTorch) allocates every buffer and workspace; the library
  *    borrows pointers for the duration of a call and never allocates or frees.
- *  - Every call takes the HIP stream explicitly; no global state, re-entrant.
+ *  - Every call takes the HIP stream explicitly; host side re-entrant, no host-side global state apart from the
+ *    lazily loaded RCCL entry points of mt_comm_*.  One device-side exception: the scalar loss reductions (mt_bce_*_fwd,
+ *    mt_gan_const_fwd, mt_l1_fwd, mt_l2mean_fwd, mt_kl_fwd) combine their block partials through a module-level scratch
+ *    (fixed-order, reproducible sums without float atomics), so those calls must be stream-ordered with respect to each
+ *    other -- issue them on one stream, as the step does.
  *  - Return value: 0 on success, non-zero on error; mt_last_error() gives a thread-local
  *    message.  No C++ exception crosses the ABI.
  */
