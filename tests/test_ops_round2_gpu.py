@@ -211,3 +211,49 @@ def test_linear_grouped_matches_separate_layers(fused, hip_device):
     for k in range(G):
         assert (Wd[k].grad.cpu().double() - off - Wr[k].grad).abs().max().item() < 1e-4, k
         assert (Bd[k].grad.cpu().double() - off - Br[k].grad).abs().max().item() < 1e-4, k
+
+
+PACK_DESCS = [
+    # transposed, N, H, W, Ci, Co, k, stride, pad, pad_mode, out_pad
+    (0, 2, 16, 16, 256, 256, 3, 1, 1, 1, 0),        # K1: forward image + ring data-gradient image (25 tap runs)
+    (0, 2, 16, 16, 64, 128, 3, 2, 1, 1, 0),         # stride 2: four sub-pixel phase images for the data gradient
+    (0, 2, 16, 16, 520, 1030, 4, 2, 1, 0, 0),       # 4x4, channel counts that are not multiples of the tiles
+    (0, 2, 32, 32, 3, 64, 7, 1, 3, 1, 0),           # stem: 49 taps, 3 input channels
+    (1, 2, 16, 16, 128, 64, 3, 2, 1, 0, 1),         # ConvTranspose2d (IOHW): "rows near" forward image
+    (0, 2, 8, 8, 1024, 1024, 3, 2, 1, 1, 0),
+    (0, 2, 8, 8, 256, 256, 1, 1, 0, 0, 0),          # 1x1
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", PACK_DESCS, ids=[f"{'T' if c[0] else 'C'}{c[4]}x{c[5]}k{c[6]}s{c[7]}" for c in PACK_DESCS])
+def test_batched_weight_pack_equals_single_pack(case, dtype, hip_device):
+    """mt_conv_pack_multi_* (LDS-staged tiles, one launch for many images) must produce byte-identical images to
+    mt_conv_pack (one element per thread) for forward and data-gradient packs of every layout the step uses."""
+    L, lib = _lib()
+    tr, N, H, W, Ci, Co, k, st, pad, pm, op = case
+    mt = L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32
+    desc = L.ConvDesc(mt, tr, N, H, W, Ci, Co, k, k, st, pad, pm, op, L.ACT_NONE, 0.01)
+    g = torch.Generator().manual_seed(Ci + Co + k)
+    shape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = torch.randn(shape, generator=g).to(hip_device)
+    singles, packs = [], []
+    for which in (L.PACK_FWD, L.PACK_BWD_DATA):
+        nb = max(int(lib.mt_conv_pack_bytes(C.byref(desc), which)), 16)
+        a = torch.full((nb,), 0x5A, dtype=torch.uint8, device=hip_device)
+        L.check(lib.mt_conv_pack(C.byref(desc), which, P(w), P(a), S()), "mt_conv_pack")
+        singles.append(a)
+        packs.append(torch.full((nb,), 0xA5, dtype=torch.uint8, device=hip_device))
+    n = 2
+    descs = (L.ConvDesc * n)(desc, desc)
+    whichs = (C.c_int * n)(L.PACK_FWD, L.PACK_BWD_DATA)
+    ws = (C.c_void_p * n)(w.data_ptr(), w.data_ptr())
+    pk = (C.c_void_p * n)(packs[0].data_ptr(), packs[1].data_ptr())
+    host = C.create_string_buffer(int(lib.mt_conv_pack_multi_table_bytes(n)))
+    ne, nblk = C.c_int(), C.c_int()
+    L.check(lib.mt_conv_pack_multi_build(n, descs, whichs, ws, pk, host, C.byref(ne), C.byref(nblk)), "build")
+    dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(hip_device)
+    L.check(lib.mt_conv_pack_multi_run(P(dev), ne.value, nblk.value, S()), "run")
+    torch.cuda.synchronize()
+    for which, a, b in zip(("fwd", "bwd_data"), singles, packs):
+        assert torch.equal(a, b), f"{which}: batched pack differs in {(a != b).sum().item()} of {a.numel()} bytes"
