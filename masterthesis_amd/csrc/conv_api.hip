@@ -173,7 +173,7 @@ extern "C" int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const 
       PackEntry& e = tab[ne++];
       e.p = p; e.w = w[i]; e.out = (char*)packs[i] + off; e.bf16 = d->dtype == MT_BF16;
       e.blk0 = blocks;
-      mt_pack_plan(&e);                     // tiling mode + number of blocks of this image
+      e.nblk = (int)(total + 255) / 256 < 2048 ? (int)((total + 255) / 256) : 2048;
       blocks += e.nblk;
       return 0;
     });

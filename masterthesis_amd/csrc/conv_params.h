@@ -101,13 +101,7 @@ struct PackEntry {
   void* out;
   int bf16;
   int blk0, nblk;   // blocks [blk0, blk0 + nblk) of the launch belong to this entry
-  // tiling of the LDS-staged variants (mt_pack_plan): mode 0 = element per thread (any strides); 1 = "columns near"
-  // (sc == K2: a block stages the contiguous run of CB columns x K2 taps of ONE row); 2 = "rows near" (sr == K2: a block
-  // stages, for CB columns, the contiguous run of RB rows x K2 taps each)
-  int mode, K2, RB, CB, tiles_c;
 };
-// fills mode / K2 / RB / CB / tiles_c / nblk of an entry whose PackParams are set
-void mt_pack_plan(PackEntry* e);
 int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s);
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s);

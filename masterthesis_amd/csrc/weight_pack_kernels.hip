@@ -22,24 +22,8 @@ __global__ void pack_kernel(const float* __restrict__ w, void* __restrict__ out,
     else reinterpret_cast<float*>(out)[i] = v;
   }
 }
-// batched variant: the table lives in device memory (built once per network, addresses are stable).
-// The element-per-thread mapping reads 4 bytes out of every K2*4 of a reference-layout tensor and touches every cache
-// line once per tap (614 MB of L2->L1 traffic for a 63 MB discriminator, 122 us).  Modes 1 / 2 stage the CONTIGUOUS run
-// of the source that a tile needs through a small LDS buffer with coalesced loads and write 128-byte runs of the packed
-// image; the row stride of the LDS image is made odd so the transposed reads are bank-conflict free.
-#define MT_PACK_LDS_FLOATS 8192
-__device__ __forceinline__ void pack_store(const PackEntry& e, long o, float v) {
-  if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[o] = f32_to_bf16_bits(v);
-  else reinterpret_cast<float*>(e.out)[o] = v;
-}
-// exact i / d for 0 <= i < 2^20 / d ... (i * ceil(2^20 / d)) >> 20 is exact while i * d_err < 2^20; the tiles here have
-// i < 8192 * 2 and d <= 127, checked on the host (mt_pack_plan keeps LDS tiles <= 8192 floats)
-__device__ __forceinline__ int fast_div(int i, unsigned inv) { return (int)(((unsigned long long)(unsigned)i * inv) >> 32); }
-__device__ __forceinline__ unsigned div_magic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
-
-#define MT_PACK_TILES_PER_BLOCK 4
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
-  __shared__ float lds[MT_PACK_LDS_FLOATS];
+// batched variant: the table lives in device memory (built once per network, addresses are stable)
+__global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
   int lo = 0, hi = n - 1;                       // entry whose block range holds blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -47,94 +31,17 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackEntry* __rest
   }
   const PackEntry& e = tab[lo];
   const PackParams& p = e.p;
-  const float* __restrict__ w = e.w;
-  const int blk = blockIdx.x - e.blk0;
-  const int tid = threadIdx.x;
-  if (e.mode == 0) {
-    const long total = (long)p.Rp * p.ntaps * p.Cp;
-    for (long i = (long)blk * 256 + tid; i < total; i += (long)e.nblk * 256) {
-      const int c = (int)(i % p.Cp);
-      const long rt = i / p.Cp;
-      const int t = (int)(rt % p.ntaps);
-      const int r = (int)(rt / p.ntaps);
-      float v = 0.f;
-      if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
-      pack_store(e, i, v);
-    }
-    return;
-  }
-  const int K2 = e.K2, CB = e.CB, cb_shift = 31 - __builtin_clz(CB);      // CB is a power of two
-  const unsigned inv_nt = div_magic(p.ntaps);
-  const int ntiles = e.mode == 1 ? p.Rp * e.tiles_c : ((p.Rp + e.RB - 1) / e.RB) * e.tiles_c;
-  for (int tile = blk * MT_PACK_TILES_PER_BLOCK; tile < min(ntiles, (blk + 1) * MT_PACK_TILES_PER_BLOCK); tile++) {
-    const int tr = tile / e.tiles_c, c0 = (tile - tr * e.tiles_c) * CB;
-    const int ncl = min(CB, p.C - c0), ncols = min(CB, p.Cp - c0);
-    __syncthreads();                                       // previous tile's LDS image is no longer read
-    if (e.mode == 1) {
-      // one row r, columns [c0, c0 + CB): source floats [r*sr + c0*K2, r*sr + (c0+CB)*K2) are contiguous; they are
-      // copied linearly (lds[cl*K2 + k]); K2 is odd for the 3x3 / 7x7 / 1x1 filters (conflict-free column reads)
-      const int r = tr;
-      if (r < p.R && ncl > 0) {
-        const float* src = w + (long)r * p.sr + (long)c0 * K2;
-        for (int i = tid; i < ncl * K2; i += 256) lds[i] = src[i];
-      }
-      __syncthreads();
-      for (int idx = tid; idx < (p.ntaps << cb_shift); idx += 256) {
-        const int t = idx >> cb_shift, cl = idx & (CB - 1);
-        if (cl >= ncols) continue;
-        float v = 0.f;
-        if (r < p.R && cl < ncl) v = lds[cl * K2 + p.kh[t] * p.kW + p.kw[t]];
-        pack_store(e, ((long)r * p.ntaps + t) * p.Cp + c0 + cl, v);
-      }
-    } else {
-      // rows [r0, r0 + RB), columns [c0, c0 + CB): per column the floats [c*sc + r0*K2, c*sc + (r0+RB)*K2) are contiguous
-      const int RB = e.RB, S = (RB * K2) | 1;
-      const int r0 = tr * RB;
-      const int nrl = min(RB, p.R - r0), nrows = min(RB, p.Rp - r0);
-      if (nrl > 0 && ncl > 0) {
-        const int len = nrl * K2;
-        const unsigned inv_len = div_magic(len);
-        for (int i = tid; i < ncl * len; i += 256) {
-          const int cl = fast_div(i, inv_len), j = i - cl * len;
-          lds[cl * S + j] = w[(long)(c0 + cl) * p.sc + (long)r0 * K2 + j];
-        }
-      }
-      __syncthreads();
-      for (int idx = tid; idx < ((nrows * p.ntaps) << cb_shift); idx += 256) {
-        const int cl = idx & (CB - 1), rt = idx >> cb_shift;
-        if (cl >= ncols) continue;
-        const int rl = fast_div(rt, inv_nt), t = rt - rl * p.ntaps;
-        float v = 0.f;
-        if (rl < nrl && cl < ncl) v = lds[cl * S + rl * K2 + p.kh[t] * p.kW + p.kw[t]];
-        pack_store(e, ((long)(r0 + rl) * p.ntaps + t) * p.Cp + c0 + cl, v);
-      }
-    }
-  }
-}
-void mt_pack_plan(PackEntry* e) {
-  const PackParams& p = e->p;
   const long total = (long)p.Rp * p.ntaps * p.Cp;
-  // K2 = taps of the full filter = the shorter of the two strides (the other one is a multiple of it)
-  const long K2 = p.sr < p.sc ? p.sr : p.sc;
-  int maxoff = 0;
-  for (int t = 0; t < p.ntaps; t++) { const int o = p.kh[t] * p.kW + p.kw[t]; maxoff = o > maxoff ? o : maxoff; }
-  e->mode = 0; e->K2 = (int)K2; e->RB = 1; e->CB = 1; e->tiles_c = 1;
-  e->nblk = (total + 255) / 256 < 2048 ? (int)((total + 255) / 256) : 2048;
-  if (total < 16384 || K2 < 1 || K2 > 64 || maxoff >= K2) return;            // tiny images / unexpected layouts: element-wise
-  if (p.sc == K2 && p.sr >= (long)p.C * K2) {
-    int CB = 128;
-    while (CB > 8 && (long)CB * K2 > MT_PACK_LDS_FLOATS) CB >>= 1;
-    if ((long)CB * K2 > MT_PACK_LDS_FLOATS) return;
-    e->mode = 1; e->CB = CB; e->tiles_c = (p.Cp + CB - 1) / CB;
-    e->nblk = (p.Rp * e->tiles_c + MT_PACK_TILES_PER_BLOCK - 1) / MT_PACK_TILES_PER_BLOCK;
-  } else if (p.sr == K2 && p.sc >= (long)p.R * K2) {
-    const int CB = 64;
-    int RB = (int)(127 / K2);
-    if (RB > 8) RB = 8;
-    if (RB < 1) return;
-    if ((long)CB * ((RB * K2) | 1) > MT_PACK_LDS_FLOATS) return;
-    e->mode = 2; e->CB = CB; e->RB = RB; e->tiles_c = (p.Cp + CB - 1) / CB;
-    e->nblk = (((p.Rp + RB - 1) / RB) * e->tiles_c + MT_PACK_TILES_PER_BLOCK - 1) / MT_PACK_TILES_PER_BLOCK;
+  const float* __restrict__ w = e.w;
+  for (long i = (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; i < total; i += (long)e.nblk * blockDim.x) {
+    const int c = (int)(i % p.Cp);
+    const long rt = i / p.Cp;
+    const int t = (int)(rt % p.ntaps);
+    const int r = (int)(rt / p.ntaps);
+    float v = 0.f;
+    if (r < p.R && c < p.C) v = w[(long)r * p.sr + (long)c * p.sc + p.kh[t] * p.kW + p.kw[t]];
+    if (e.bf16) reinterpret_cast<unsigned short*>(e.out)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(e.out)[i] = v;
   }
 }
 int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s) {
