@@ -160,13 +160,6 @@ int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const 
                          const float* gb, const float* gamma, float* c1, float* c2, float* c3,
                          float* dgb, float* dgamma, float* dbeta, int N, int HW, int C, int Cp,
                          int nparts, mt_stream_t s);
-/* mt_nc_stats_bwd + mt_norm_bwd_finalize in one launch (INSTANCE / ADAIN / LAYER; N <= 4096): the block that publishes
- * the last partial row of an image computes that image's coefficients.  part: workspace of
- * N * mt_nc_stats_parts(dtype, N, HW, Cp) * Cp * 2 floats.  Same outputs, same (fixed) summation order class. */
-int mt_nc_stats_bwd_finalize(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
-                             const float* mean, const float* rstd, const float* gb, const float* gamma, float* part,
-                             float* c1, float* c2, float* c3, float* dgb, float* dgamma, float* dbeta, int N, int HW, int C,
-                             int Cp, int act, float slope, mt_stream_t s);
 int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
                       const float* shift, const float* c1, const float* c2, const float* c3,
                       void* dx, int N, int HW, int Cp, int act, float slope, mt_stream_t s);

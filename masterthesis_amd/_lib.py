@@ -56,8 +56,6 @@ SIGNATURES = {
     "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_conv_fwd_stats_fused": (_i, [_dp]),
     "mt_nc_stats_parts": (_i, [_i, _i, _i, _i]),
-    "mt_nc_stats_bwd_finalize": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
-                                      _f, _p]),
     "mt_norm_apply_fused": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
     "mt_act_bwd_bias_ws_bytes": (_z, [_i]),
     "mt_act_bwd_bias": (_i, [_i, _p, _p, _p, _z, _i, _i, _i, _f, _p, _i, _p, _z, _p]),

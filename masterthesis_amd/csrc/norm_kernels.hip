@@ -11,7 +11,6 @@
 // Statistics are fp32 and REPRODUCIBLE: a block reduces its pixel range in a fixed order and writes one partial
 // row [Cp][2]; the finalize kernels add the rows of an image in index order.  No atomics, nothing to zero.
 #include "mt_common.h"
-#include <string.h>
 
 // Geometry shared by the statistics kernels: 256 threads = npl pixel lanes x cchunks 16-byte channel chunks,
 // nparts pixel blocks per image (<= 64), about eight blocks per CU for the big maps.
@@ -36,135 +35,6 @@ extern "C" int mt_nc_stats_parts(int dtype, int N, int HW, int Cp) {
   return nparts;
 }
 
-// Per-image totals of the partial rows in LDS: tot[c] = {sum, sum2} of (n, c).  T threads; with G = T / Cp
-// thread groups (Cp <= FIN_T) group g adds rows g, g+G, ... and the groups are then added in index order -- a fixed
-// order, independent of scheduling.  Cp <= MT_FIN_MAXC.
-#define FIN_T 1024
-#define MT_FIN_MAXC 2048
-// COHERENT: the rows were written by other blocks of the SAME launch (fused statistics + finalize): read them at device
-// scope, past this CU's L1 (a 128-byte line can hold rows of two images when Cp = 8)
-template <bool COHERENT>
-__device__ __forceinline__ float2 load_row_elem(const float2* q) {
-  if constexpr (COHERENT) {
-    const float* f = reinterpret_cast<const float*>(q);
-    return make_float2(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                       __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else {
-    return *q;
-  }
-}
-template <int T, bool COHERENT = false>
-__device__ __forceinline__ void combine_parts(const float* __restrict__ part, int n, int nparts, int Cp,
-                                              float2* __restrict__ tot, float2* __restrict__ scratch) {
-  const int t = threadIdx.x;
-  const float2* p = (const float2*)part + ((long)n * nparts) * Cp;
-  if (nparts == 1) {
-    for (int c = t; c < Cp; c += T) tot[c] = load_row_elem<COHERENT>(p + c);
-  } else if (Cp <= T) {
-    const int G = T / Cp;
-    const int c = t % Cp, g = t / Cp;
-    float sa = 0.f, sb = 0.f;
-    if (g < G) {
-#pragma unroll 4
-      for (int k = g; k < nparts; k += G) {
-        const float2 v = load_row_elem<COHERENT>(p + (long)k * Cp + c);
-        sa += v.x; sb += v.y;
-      }
-    }
-    scratch[t] = make_float2(sa, sb);
-    __syncthreads();
-    if (t < Cp) {
-      float ta = 0.f, tb = 0.f;
-      for (int j = 0; j < G; j++) { const float2 v = scratch[t + j * Cp]; ta += v.x; tb += v.y; }
-      tot[t] = make_float2(ta, tb);
-    }
-  } else {
-    for (int c = t; c < Cp; c += T) {
-      float sa = 0.f, sb = 0.f;
-#pragma unroll 4
-      for (int k = 0; k < nparts; k++) { const float2 v = load_row_elem<COHERENT>(p + (long)k * Cp + c); sa += v.x; sb += v.y; }
-      tot[c] = make_float2(sa, sb);
-    }
-  }
-  __syncthreads();
-}
-
-// Backward coefficients of ONE image from its summed statistics (tot, in LDS); T threads.  With xh = (x-m)*r, a = per-(n,c)
-// multiplier of xh in the forward (1, 1+gamma_adain or gamma_layer), S1 = sum g, S2 = sum g*x over the pixels:
-//   sum g*xh = r*(S2 - m*S1)
-//   INSTANCE/ADAIN: dx = r*a*(g - S1/HW - xh * sum(g*xh)/HW)
-//   LAYER         : dx = r*(a*g - A/(C*HW) - xh * B/(C*HW)),  A = sum_c a_c*S1_c, B = sum_c a_c*sum(g*xh)_c
-template <int T>
-__device__ __forceinline__ void norm_bwd_finalize_body(int mode, int n, const float2* __restrict__ tot,
-                                                       float (*red)[T / 64], float* bc, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ gb,
-                                                       const float* __restrict__ gamma, float* __restrict__ c1,
-                                                       float* __restrict__ c2, float* __restrict__ c3,
-                                                       float* __restrict__ dgb, int HW, int C, int Cp) {
-  float LA = 0.f, LB = 0.f;
-  if (mode == MT_NORM_LAYER) {
-    float a = 0.f, b = 0.f;
-    for (int c = threadIdx.x; c < C; c += T) {
-      const long i = (long)n * Cp + c;
-      const float S1 = tot[c].x, S2 = tot[c].y;
-      const float gxh = rstd[i] * (S2 - mean[i] * S1);
-      const float g = gamma ? gamma[c] : 1.f;
-      a += g * S1; b += g * gxh;
-      if (dgb) { dgb[(long)n * 2 * C + c] = gxh; dgb[(long)n * 2 * C + C + c] = S1; }   // per-image terms of dgamma, dbeta
-    }
-    a = wave_sum(a); b = wave_sum(b);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float ta = 0.f, tb = 0.f;
-      for (int k = 0; k < (int)(T >> 6); k++) { ta += red[0][k]; tb += red[1][k]; }
-      bc[0] = ta; bc[1] = tb;
-    }
-    __syncthreads();
-    LA = bc[0]; LB = bc[1];
-  }
-  for (int c = threadIdx.x; c < Cp; c += T) {
-    const long i = (long)n * Cp + c;
-    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
-    if (c < C) {
-      const float m = mean[i], r = rstd[i];
-      const float S1 = tot[c].x, S2 = tot[c].y;
-      const float gxh = r * (S2 - m * S1);
-      if (mode == MT_NORM_LAYER) {
-        const float g = gamma ? gamma[c] : 1.f;
-        const float cnt = (float)C * (float)HW;
-        // dx = r*g*gval - r*LA/cnt - r*(x-m)*r*LB/cnt
-        k1 = r * g;
-        k3 = -r * r * LB / cnt;
-        k2 = -r * LA / cnt - k3 * m;
-      } else {
-        float a = 1.f;
-        if (mode == MT_NORM_ADAIN) {
-          a = 1.f + gb[(long)n * 2 * C + c];
-          dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
-          dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
-        }
-        const float hw = (float)HW;
-        k1 = r * a;
-        k3 = -r * a * r * gxh / hw;
-        k2 = -r * a * S1 / hw - k3 * m;
-      }
-    }
-    c1[i] = k1; c2[i] = k2; c3[i] = k3;
-  }
-}
-
-// Optional tail of the backward statistics kernel: the block that finishes an image LAST (per-image ticket) also
-// computes that image's backward coefficients, so norm backward is two launches (statistics + finalize, apply)
-// instead of three.  Nobody waits for anybody: no spinning, a block only learns whether it was the last one.
-struct BwdFinArgs {
-  int enable, mode, C;
-  const float *mean, *rstd, *gb, *gamma;
-  float *c1, *c2, *c3, *dgb;
-};
-#define MT_MAX_TICKET_IMAGES 4096
-__device__ unsigned g_norm_tickets[MT_MAX_TICKET_IMAGES];
-
 // grid = (nparts, N).  Thread (pl, cq) walks pixels p0 + pl, p0 + pl + npl, ... with U independent 16-byte loads
 // (2U backward) in flight, then ONE pass through LDS combines the pixel lanes in a fixed order.
 template <bool BF16, bool BWD>
@@ -172,7 +42,7 @@ __global__ __launch_bounds__(256) void nc_stats_kernel(const u32x4* __restrict__
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, float* __restrict__ part,
                                                       int HW, int cchunks, int pix_per_block, int act,
-                                                      float slope, const BwdFinArgs fin) {
+                                                      float slope) {
   constexpr int V = Elem<BF16>::V;
   constexpr int NV = 2 * V;
   constexpr int U = 4;
@@ -266,39 +136,11 @@ __global__ __launch_bounds__(256) void nc_stats_kernel(const u32x4* __restrict__
     for (int r = 0; r < rows; r++) a += row[r * cchunks];
     dst[o] = a;
   }
-  if constexpr (BWD) {
-    if (fin.enable) {
-      // last block of this image?  (the ticket counts the blocks of image n that have published their row)
-      __shared__ int s_last;
-      __shared__ float2 scratch[256];
-      __shared__ float redw[2][4];
-      __shared__ float bc[2];
-      __threadfence();
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned t = atomicAdd(&g_norm_tickets[n], 1u);
-        s_last = (t == gridDim.x - 1) ? 1 : 0;
-        if (s_last) g_norm_tickets[n] = 0;                  // ready for the next launch (stream ordered)
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        float2* tot = reinterpret_cast<float2*>(red);       // NV*STR floats >= 2*Cp (Cp <= 2048 checked on the host)
-        combine_parts<256, true>(part, n, gridDim.x, Cp, tot, scratch);
-        norm_bwd_finalize_body<256>(fin.mode, n, tot, redw, bc, fin.mean, fin.rstd, fin.gb, fin.gamma, fin.c1, fin.c2,
-                                    fin.c3, fin.dgb, HW, fin.C, Cp);
-      }
-    }
-  }
 }
 
 template <bool BWD>
 static int launch_stats(int dtype, const void* x, const void* dy, const float* scale, const float* shift,
-                        float* part, int N, int HW, int Cp, int act, float slope, hipStream_t s,
-                        const BwdFinArgs* finp = nullptr) {
-  BwdFinArgs fin;
-  memset(&fin, 0, sizeof(fin));
-  if (finp) fin = *finp;
+                        float* part, int N, int HW, int Cp, int act, float slope, hipStream_t s) {
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int cchunks = Cp / V;
   MT_CHECK(Cp % 8 == 0 && cchunks >= 1 && cchunks <= 256, "nc_stats: unsupported channel count %d", Cp);
@@ -307,9 +149,9 @@ static int launch_stats(int dtype, const void* x, const void* dy, const float* s
   stats_geometry(N, HW, cchunks, &ppb, &nparts);
   dim3 grid(nparts, N);
   if (dtype == MT_BF16)
-    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope, fin);
+    hipLaunchKernelGGL((nc_stats_kernel<true, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope);
   else
-    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope, fin);
+    hipLaunchKernelGGL((nc_stats_kernel<false, BWD>), grid, dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, scale, shift, part, HW, cchunks, ppb, act, slope);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -334,6 +176,46 @@ __device__ __forceinline__ void load_sums(const float* __restrict__ part, int n,
   a = sa; b = sb;
 }
 
+// Per-image totals of the partial rows in LDS: tot[c] = {sum, sum2} of (n, c).  FIN_T threads; with G = FIN_T / Cp
+// thread groups (Cp <= FIN_T) group g adds rows g, g+G, ... and the groups are then added in index order -- a fixed
+// order, independent of scheduling.  Cp <= MT_FIN_MAXC.
+#define FIN_T 1024
+#define MT_FIN_MAXC 2048
+__device__ __forceinline__ void combine_parts(const float* __restrict__ part, int n, int nparts, int Cp,
+                                              float2* __restrict__ tot, float2* __restrict__ scratch) {
+  const int t = threadIdx.x;
+  const float2* p = (const float2*)part + ((long)n * nparts) * Cp;
+  if (nparts == 1) {
+    for (int c = t; c < Cp; c += FIN_T) tot[c] = p[c];
+  } else if (Cp <= FIN_T) {
+    const int G = FIN_T / Cp;
+    const int c = t % Cp, g = t / Cp;
+    float sa = 0.f, sb = 0.f;
+    if (g < G) {
+#pragma unroll 4
+      for (int k = g; k < nparts; k += G) {
+        const float2 v = p[(long)k * Cp + c];
+        sa += v.x; sb += v.y;
+      }
+    }
+    scratch[t] = make_float2(sa, sb);
+    __syncthreads();
+    if (t < Cp) {
+      float ta = 0.f, tb = 0.f;
+      for (int j = 0; j < G; j++) { const float2 v = scratch[t + j * Cp]; ta += v.x; tb += v.y; }
+      tot[t] = make_float2(ta, tb);
+    }
+  } else {
+    for (int c = t; c < Cp; c += FIN_T) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < nparts; k++) { const float2 v = p[(long)k * Cp + c]; sa += v.x; sb += v.y; }
+      tot[c] = make_float2(sa, sb);
+    }
+  }
+  __syncthreads();
+}
+
 // one block per sample; threads stride over channels
 __global__ __launch_bounds__(FIN_T) void norm_finalize_kernel(int mode, const float* __restrict__ sums, const float* __restrict__ gb,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -345,7 +227,7 @@ __global__ __launch_bounds__(FIN_T) void norm_finalize_kernel(int mode, const fl
   __shared__ float bc[2];
   __shared__ float2 tot[MT_FIN_MAXC];
   __shared__ float2 scratch[FIN_T];
-  combine_parts<FIN_T>(sums, n, nparts, Cp, tot, scratch);
+  combine_parts(sums, n, nparts, Cp, tot, scratch);
   float lmean = 0.f, lrstd = 0.f;
   if (mode == MT_NORM_LAYER) {
     float a = 0.f, b = 0.f;
@@ -604,6 +486,11 @@ extern "C" int mt_norm_apply_fused(int dtype, int mode, const void* x, const flo
   return 0;
 }
 
+// Backward coefficients.  With xh = (x-m)*r, a = per-(n,c) multiplier of xh in the forward
+// (1, 1+gamma_adain or gamma_layer), S1 = sum g, S2 = sum g*x over the pixels:
+//   sum g*xh = r*(S2 - m*S1)
+//   INSTANCE/ADAIN: dx = r*a*(g - S1/HW - xh * sum(g*xh)/HW)
+//   LAYER         : dx = r*(a*g - A/(C*HW) - xh * B/(C*HW)),  A = sum_c a_c*S1_c, B = sum_c a_c*sum(g*xh)_c
 __global__ __launch_bounds__(FIN_T) void norm_bwd_finalize_kernel(int mode, const float* __restrict__ sums2,
                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gb, const float* __restrict__ gamma,
@@ -614,8 +501,58 @@ __global__ __launch_bounds__(FIN_T) void norm_bwd_finalize_kernel(int mode, cons
   __shared__ float bc[2];
   __shared__ float2 tot[MT_FIN_MAXC];
   __shared__ float2 scratch[FIN_T];
-  combine_parts<FIN_T>(sums2, n, nparts, Cp, tot, scratch);
-  norm_bwd_finalize_body<FIN_T>(mode, n, tot, red, bc, mean, rstd, gb, gamma, c1, c2, c3, dgb, HW, C, Cp);
+  combine_parts(sums2, n, nparts, Cp, tot, scratch);
+  float LA = 0.f, LB = 0.f;
+  if (mode == MT_NORM_LAYER) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const long i = (long)n * Cp + c;
+      const float S1 = tot[c].x, S2 = tot[c].y;
+      const float gxh = rstd[i] * (S2 - mean[i] * S1);
+      const float g = gamma ? gamma[c] : 1.f;
+      a += g * S1; b += g * gxh;
+      if (dgb) { dgb[(long)n * 2 * C + c] = gxh; dgb[(long)n * 2 * C + C + c] = S1; }   // per-image terms of dgamma, dbeta
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ta = 0.f, tb = 0.f;
+      for (int k = 0; k < (int)(blockDim.x >> 6); k++) { ta += red[0][k]; tb += red[1][k]; }
+      bc[0] = ta; bc[1] = tb;
+    }
+    __syncthreads();
+    LA = bc[0]; LB = bc[1];
+  }
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const long i = (long)n * Cp + c;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (c < C) {
+      const float m = mean[i], r = rstd[i];
+      const float S1 = tot[c].x, S2 = tot[c].y;
+      const float gxh = r * (S2 - m * S1);
+      if (mode == MT_NORM_LAYER) {
+        const float g = gamma ? gamma[c] : 1.f;
+        const float cnt = (float)C * (float)HW;
+        // dx = r*g*gval - r*LA/cnt - r*(x-m)*r*LB/cnt
+        k1 = r * g;
+        k3 = -r * r * LB / cnt;
+        k2 = -r * LA / cnt - k3 * m;
+      } else {
+        float a = 1.f;
+        if (mode == MT_NORM_ADAIN) {
+          a = 1.f + gb[(long)n * 2 * C + c];
+          dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
+          dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
+        }
+        const float hw = (float)HW;
+        k1 = r * a;
+        k3 = -r * a * r * gxh / hw;
+        k2 = -r * a * S1 / hw - k3 * m;
+      }
+    }
+    c1[i] = k1; c2[i] = k2; c3[i] = k3;
+  }
 }
 // LayerNorm affine gradients from the per-image terms the finalize kernel left in pg [N][2][C]:
 // dgamma[c] = sum_n pg[n][0][c], dbeta[c] = sum_n pg[n][1][c], images added in index order (reproducible)
@@ -639,32 +576,6 @@ extern "C" int mt_norm_bwd_finalize(int mode, const float* sums2, const float* m
   MT_CHECK(nparts >= 1 && Cp <= MT_FIN_MAXC, "norm_bwd_finalize: nparts %d, Cp %d", nparts, Cp);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(N), dim3(FIN_T), 0, s, mode, sums2, mean, rstd, gb, gamma, c1, c2, c3, dgb, HW, C, Cp, nparts);
   MT_LAUNCH_CHECK();
-  if (mode == MT_NORM_LAYER && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dgb, dgamma, dbeta, N, C);
-    MT_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-// mt_nc_stats_bwd + mt_norm_bwd_finalize in ONE launch (modes INSTANCE / ADAIN / LAYER): the block that publishes the last
-// partial row of an image computes that image's coefficients (see BwdFinArgs).  part: workspace [N][nparts][Cp][2].
-extern "C" int mt_nc_stats_bwd_finalize(int dtype, int mode, const void* dy, const void* x, const float* scale,
-                                        const float* shift, const float* mean, const float* rstd, const float* gb,
-                                        const float* gamma, float* part, float* c1, float* c2, float* c3, float* dgb,
-                                        float* dgamma, float* dbeta, int N, int HW, int C, int Cp, int act, float slope,
-                                        mt_stream_t st) {
-  hipStream_t s = (hipStream_t)st;
-  MT_CHECK(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN || mode == MT_NORM_LAYER, "nc_stats_bwd_finalize: bad mode %d", mode);
-  MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "nc_stats_bwd_finalize: adain needs gb/dgb");
-  MT_CHECK(mode != MT_NORM_LAYER || !(dgamma || dbeta) || dgb != nullptr,
-           "nc_stats_bwd_finalize: layer norm with affine gradients needs the [N][2][C] scratch in dgb");
-  MT_CHECK(N <= MT_MAX_TICKET_IMAGES && Cp <= MT_FIN_MAXC, "nc_stats_bwd_finalize: N %d / Cp %d out of range", N, Cp);
-  BwdFinArgs fin;
-  memset(&fin, 0, sizeof(fin));
-  fin.enable = 1; fin.mode = mode; fin.C = C;
-  fin.mean = mean; fin.rstd = rstd; fin.gb = gb; fin.gamma = gamma;
-  fin.c1 = c1; fin.c2 = c2; fin.c3 = c3; fin.dgb = dgb;
-  if (launch_stats<true>(dtype, x, dy, scale, shift, part, N, HW, Cp, act, slope, s, &fin)) return 2;
   if (mode == MT_NORM_LAYER && (dgamma || dbeta)) {
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dgb, dgamma, dbeta, N, C);
     MT_LAUNCH_CHECK();

@@ -767,6 +767,8 @@ class _Norm(torch.autograd.Function):
         mt = _mt(x.dtype)
         nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
         sums2 = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)
+        L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
+                                    slope, _stream()), "mt_nc_stats_bwd")
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
         dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
         dgamma = dbeta = None
@@ -775,23 +777,14 @@ class _Norm(torch.autograd.Function):
             dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
             if mode == L.NORM_LAYER:
                 dgb = torch.empty((N, 2, Cc), dtype=torch.float32, device=dev)      # per-image terms of dgamma / dbeta
-        if mode != L.NORM_BATCH and N <= 4096:
-            # statistics + coefficients in ONE launch: the block that publishes an image's last partial row finalizes it
-            L.check(lib.mt_nc_stats_bwd_finalize(mt, mode, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]),
-                                                 _ptr(coef[3]), _ptr(gbc), _ptr(gm), _ptr(sums2), _ptr(cc[0]), _ptr(cc[1]),
-                                                 _ptr(cc[2]), _ptr(dgb), _ptr(dgamma), _ptr(dbeta), N, HW, Cc, Cp, act, slope,
-                                                 _stream()), "mt_nc_stats_bwd_finalize")
+        if mode == L.NORM_BATCH:
+            L.check(lib.mt_bn_bwd_finalize(_ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gm), _ptr(cc[0]), _ptr(cc[1]),
+                                           _ptr(cc[2]), _ptr(dgamma), _ptr(dbeta), int(ctx.cfg[4][3]), N, HW, Cc, Cp,
+                                           nparts, _stream()), "mt_bn_bwd_finalize")
         else:
-            L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
-                                        slope, _stream()), "mt_nc_stats_bwd")
-            if mode == L.NORM_BATCH:
-                L.check(lib.mt_bn_bwd_finalize(_ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gm), _ptr(cc[0]), _ptr(cc[1]),
-                                               _ptr(cc[2]), _ptr(dgamma), _ptr(dbeta), int(ctx.cfg[4][3]), N, HW, Cc, Cp,
-                                               nparts, _stream()), "mt_bn_bwd_finalize")
-            else:
-                L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
-                                                 _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
-                                                 _ptr(dbeta), N, HW, Cc, Cp, nparts, _stream()), "mt_norm_bwd_finalize")
+            L.check(lib.mt_norm_bwd_finalize(mode, _ptr(sums2), _ptr(coef[2]), _ptr(coef[3]), _ptr(gbc), _ptr(gm),
+                                             _ptr(cc[0]), _ptr(cc[1]), _ptr(cc[2]), _ptr(dgb), _ptr(dgamma),
+                                             _ptr(dbeta), N, HW, Cc, Cp, nparts, _stream()), "mt_norm_bwd_finalize")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cc, H, W, x.dtype, dev)
