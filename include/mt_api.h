@@ -62,6 +62,13 @@ typedef struct mt_conv_desc {
 
 const char* mt_last_error(void);
 int mt_version(void);
+/* launches routed so far to a kernel variant the dispatcher chooses by problem size (tests assert that a shape class
+ * really exercised the variant it is meant to cover): which = 0 persistent gather-GEMM (conv_persist_kernel.hip) */
+long mt_kernel_variant_launches(int which);
+/* switch such a variant off / on again (tests compare it bit for bit with the kernel it replaces; both are
+ * results-identical by construction); returns the previous setting.  MT_IGEMM_PERSIST=0 in the environment disables
+ * variant 0 from the start. */
+int mt_kernel_variant_enable(int which, int enable);
 static inline int mt_padc(int c) { return (c + 7) & ~7; }
 
 /* ---- convolution family (K1-K8, K12, K17): blocks.py:10-91, networks.py ------------- */

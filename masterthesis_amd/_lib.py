@@ -38,6 +38,8 @@ _dp = C.POINTER(ConvDesc)
 SIGNATURES = {
     "mt_last_error": (C.c_char_p, []),
     "mt_version": (_i, []),
+    "mt_kernel_variant_launches": (C.c_long, [_i]),
+    "mt_kernel_variant_enable": (_i, [_i, _i]),
     "mt_conv_out_hw": (_i, [_dp, C.POINTER(_i), C.POINTER(_i)]),
     "mt_conv_pack_bytes": (_z, [_dp, _i]),
     "mt_conv_pack": (_i, [_dp, _i, _p, _p, _p]),

@@ -20,6 +20,18 @@
 // ------------------------------------------------------------------------------------------
 #include "conv_device.h"
 
+#ifdef MT_STAMPS2
+// diagnostic build only (tools/diag_build.sh NAME -DMT_STAMPS2 conv_kernels.hip): s_memtime stamps of wave 0 of every
+// block of the 2-stage kernel -> tools/stamp_layer.py
+__device__ unsigned long long mt_stamp_buf2[8 * 16384];
+#define MT_STAMP2(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) mt_stamp_buf2[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mt_debug_stamps2(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mt_stamp_buf2), bytes < sizeof(mt_stamp_buf2) ? bytes : sizeof(mt_stamp_buf2));
+}
+#else
+#define MT_STAMP2(i) do {} while (0)
+#endif
+
 // Tile geometries (WT output channels x PT pixels per block, NT threads):
 //   <128,128,256>, <64,128,256>, <32,128,256>, <16,128,256>: 4 waves, wave tile up to 64x64, 2 blocks/CU
 //   <256,256,512>: 8 waves (2 x 4), wave tile 128 channels x 64 pixels, 128 KiB LDS, 1 block/CU -- 25 % fewer
@@ -40,6 +52,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   __shared__ u32x4 sX[2][PT * 8];
   __shared__ int sTap[64];
 
+  MT_STAMP2(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -195,6 +208,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const int nk = (ph_nchunks + 7) >> 3;
   __syncthreads();  // sTap visible
   retap();
+  MT_STAMP2(1);
   if (nk > 0) issue(0);
 
   // one k-step: MFMAs on buffer `cur`; if MORE, the copies of the next k-step go out one per MFMA group,
@@ -245,8 +259,14 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
     }
     if constexpr (MORE) issue_end();
   };
+#ifdef MT_STAMPS2
+  if (nk > 1) { kstep(0, std::true_type{}); MT_STAMP2(2); }
+  for (int ks = 1; ks + 1 < nk; ks++) kstep(ks & 1, std::true_type{});
+#else
   for (int ks = 0; ks + 1 < nk; ks++) kstep(ks & 1, std::true_type{});
+#endif
   if (nk > 0) kstep((nk - 1) & 1, std::false_type{});
+  MT_STAMP2(3);
 
   // ---- epilogue: bias + activation, packed NHWC store (4 consecutive channels per lane) ----
   // per pixel fragment: output address (or null when the pixel is outside the problem / output)
@@ -397,10 +417,16 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
       }
     }
   }
+#ifdef MT_STAMPS2
+  MT_STAMP2(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MT_STAMP2(5);
+#endif
 }
 
 template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s);   // conv_pipe_kernel.hip
+int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s);          // conv_persist_kernel.hip
 
 template <bool BF16>
 static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
@@ -457,6 +483,13 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
               (total <= 256 || force == 2) && force != 1;
     for (int i = 0; i < p.nphase && ok; i++) ok = p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
     if (ok) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  }
+  // several tiles per workgroup slot: the persistent kernel pipelines across tiles (conv_persist_kernel.hip)
+  if constexpr (BF16) {
+    if (force != 1) {
+      const int r = launch_igemm_persist(p, WT, total, s);
+      if (r >= 0) return r;
+    }
   }
   if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);

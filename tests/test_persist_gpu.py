@@ -1,0 +1,85 @@
+"""The persistent gather-GEMM (csrc/conv_persist_kernel.hip) against the per-tile kernel it replaces -- bit for bit:
+both accumulate the same MFMA fragments in the same order -- and against the fp32 CPU reference of the op.
+Shapes have > 512 tiles of 128 pixels (the dispatcher's condition), ragged pixel counts, partial channel tiles,
+several sub-pixel phases (stride-2 data gradient, transposed convolution) and short reductions (1-2 k-steps)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from masterthesis_amd import _lib as L
+    return L.load()
+
+
+CASES = [
+    # name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act
+    ("k3s1_64_128", "conv", 8, 64, 128, 128, 128, 3, 1, 1, "reflect", True, "relu"),
+    ("k3s1_ragged_co192", "conv", 3, 40, 150, 151, 192, 3, 1, 1, "reflect", True, "lrelu"),
+    ("k3s1_co64_zero", "conv", 5, 24, 131, 127, 64, 3, 1, 1, "zero", False, None),
+    ("k3s2_dgrad_phases", "conv", 4, 64, 260, 258, 128, 3, 2, 1, "reflect", True, None),
+    ("k4s2_zero_msd", "conv", 5, 8, 256, 256, 64, 4, 2, 1, "zero", False, "lrelu"),
+    ("k1_short_k", "conv", 6, 64, 120, 121, 128, 1, 1, 0, "zero", True, None),
+    ("k7_stem", "conv", 4, 3, 160, 160, 64, 7, 1, 3, "reflect", True, "lrelu"),
+    ("convT_128_64", "convT", 4, 128, 96, 97, 64, 3, 2, 1, "zero", True, None),
+    ("convT_64_128", "convT", 6, 64, 80, 80, 128, 3, 2, 1, "zero", False, None),
+]
+
+
+def _run(ops, case, dev):
+    name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    wshape = (Co, Ci, k, k) if kind == "conv" else (Ci, Co, k, k)
+    w = (torch.randn(*wshape, generator=g) * (Ci * k * k) ** -0.5).bfloat16().float()
+    b = (torch.randn(Co, generator=g) * 0.1) if bias else None
+    xd = x.to(dev).requires_grad_()
+    wd = w.to(dev).requires_grad_()
+    bd = b.to(dev).requires_grad_() if bias else None
+    if kind == "conv":
+        y = ops.conv2d(xd, wd, bd, stride=stride, pad=pad, pad_mode=pad_mode, act=act)
+    else:
+        y = ops.conv_transpose2d(xd, wd, bd, stride=stride, pad=pad, out_pad=1, act=act)
+    gy = torch.randn(*y.shape, generator=g).bfloat16().float()
+    y.backward(gy.to(dev))
+    return (x, w, b, gy), (y.detach().float().cpu(), xd.grad.detach().float().cpu())
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_persistent_matches_per_tile_kernel(case, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = _lib()
+    prev = lib.mt_kernel_variant_enable(0, 1)
+    try:
+        n0 = lib.mt_kernel_variant_launches(0)
+        (x, w, b, gy), (y1, dx1) = _run(ops, case, hip_device)
+        n1 = lib.mt_kernel_variant_launches(0)
+        assert n1 > n0, "the shape was meant to run on the persistent kernel"
+        lib.mt_kernel_variant_enable(0, 0)
+        _, (y0, dx0) = _run(ops, case, hip_device)
+        assert lib.mt_kernel_variant_launches(0) == n1
+    finally:
+        lib.mt_kernel_variant_enable(0, prev)
+    assert torch.equal(y1, y0), f"forward differs: max {(y1 - y0).abs().max().item():.3e}"
+    assert torch.equal(dx1, dx0), f"data gradient differs: max {(dx1 - dx0).abs().max().item():.3e}"
+    # ... and both against the op's fp32 reference
+    name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
+    xr = x.clone().requires_grad_()
+    if kind == "conv":
+        xp = F.pad(xr, (pad,) * 4, mode="reflect") if (pad_mode == "reflect" and pad) else xr
+        yr = F.conv2d(xp, w, b, stride=stride, padding=0 if (pad_mode == "reflect" and pad) else pad)
+    else:
+        yr = F.conv_transpose2d(xr, w, b, stride=stride, padding=pad, output_padding=1)
+    if act == "relu":
+        yr = F.relu(yr)
+    elif act == "lrelu":
+        yr = F.leaky_relu(yr, 0.01)
+    yr.backward(gy)
+    for got, ref, what in ((y1, yr.detach(), "fwd"), (dx1, xr.grad, "dx")):
+        rel = (got - ref).norm().item() / (ref.norm().item() + 1e-12)
+        assert rel < 1e-2, f"{what}: rel L2 err {rel:.3e}"
+        # no tile may be missing or misplaced: the worst element error stays at bf16 rounding of the largest value
+        assert (got - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 0.02, what
