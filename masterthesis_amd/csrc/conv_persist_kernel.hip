@@ -52,11 +52,12 @@ __device__ __forceinline__ void pk_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-constexpr int MT_PERSIST_MAX_CO = 2048;   // output channels whose bias fits the LDS copy
+// output channels whose bias fits the LDS copy (the 64-channel geometry keeps its LDS under a third of the CU's)
+constexpr int persist_max_co(int WT) { return WT == 128 ? 2048 : 128; }
 
 // AUX: cache policy bits of the output stores (0 = default, 2 = nt: streaming)
 template <int WT, int BPC, int AUX>
-__global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmParams p, const int total,
+__global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmParams p, const int total, const int grp,
                                                                  const unsigned w_total, const unsigned y_total) {
   constexpr int PT = 128;
   constexpr int WC = 64, WP = WT >= 128 ? 64 : 32;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   constexpr int SPK = 2;                       // held stores issued per k-step
   constexpr int SW = WT * 8, SX = PT * 8;      // u32x4 per stage
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int MT_PERSIST_MAX_CO = persist_max_co(WT);
   static_assert(WT == 128 || WT == 64, "tile geometries of the persistent kernel");
   static_assert(NST % SPK == 0 && NST + 1 <= 9, "store groups / counted-wait range");
 
@@ -90,18 +92,26 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   const int c = (tid & 7) ^ (r0 & 7);
   const int nWT = (p.CoRows + WT - 1) / WT;
 
-  // ---- persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch); each XCD owns a contiguous
-  // eighth of the tiles and each of its blocks a contiguous run of that (consecutive tiles share halo rows / are the
-  // sub-pixel phases of one input region: the re-reads hit the XCD's L2) ----
+  // ---- persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch) and its L2; each XCD owns a
+  // contiguous eighth of the tiles.  Inside it tiles go out in groups of G consecutive tiles (the sub-pixel phases /
+  // weight tiles of ONE pixel tile: a block re-reads that input region G times from L2) and the XCD's blocks take
+  // consecutive groups, round after round: at any moment they work on one contiguous input region.  (A contiguous
+  // run of tiles per block put the 64 blocks of an XCD a power-of-two stride apart: their lines fell into the same
+  // L2 sets and half of all requests missed -- rocprofv3 TCC_HIT/TCC_MISS on the 128->64 up-convolution.) ----
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nslot = ((int)gridDim.x - xcd + 7) >> 3;
   const int tq = total >> 3, tr = total & 7;
   const int lo = xcd * tq + (xcd < tr ? xcd : tr);
   const int cnt = tq + (xcd < tr ? 1 : 0);
-  const int ipq = cnt / nslot, ipr = cnt - ipq * nslot;      // the first ipr blocks of the XCD take one tile more
-  int it = slot * ipq + (slot < ipr ? slot : ipr);
-  const int it_end = it + ipq + (slot < ipr ? 1 : 0);
-  if (it >= it_end) return;
+  const int G = grp;
+  // this block's tiles: (round * nslot + slot) * G + j,  j = 0 .. G-1, round = 0, 1, ...
+  auto tile_of = [&](int round, int j) { return (round * nslot + slot) * G + j; };
+  auto advance = [&](int& round, int& j) { j++; if (j == G) { j = 0; round++; } };
+  int it = tile_of(0, 0);
+  if (it >= cnt) return;
+  int n_round = 0, n_j = 0;                                   // ... and the one after it
+  advance(n_round, n_j);
+  int it_next = tile_of(n_round, n_j);
 
   // ---- staging state of the tile whose copies are being issued.  Per-row coordinates live in LDS tables written
   // once per tile by one thread per pixel row (the staging rows and the output rows are the same 128 pixels):
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   auto kstep = [&](int cur) {
     // the 64-channel geometry has the registers to read BOTH halves of the k-step up front (the second half's LDS
     // latency hides under the first half's MFMAs); the 128-channel one reads each half right before its MFMAs
-    constexpr int NB = (WT == 128) ? 1 : 2;
+    constexpr int NB = 2;
     u32x4 wf[NB][FC], xf[NB][FP];
     const u32x4* sWs = sWb + cur * SW;
     const u32x4* sXs = sXb + cur * SX;
@@ -288,11 +298,15 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
         const int slot_i = kc * FC + a;
         if (slot_i < NPIECE) issue_piece(cur ^ 1, slot_i);
         if (slot_i == (NPIECE < 2 * FC ? NPIECE : 2 * FC - 1)) {
+          // (the counted wait of the next k-step relies on the stores being issued AFTER the last copy: no
+          //  scheduling across this point)
+          __builtin_amdgcn_sched_barrier(0);
           if (held_grp < NST / SPK) {
             store_group(held_grp);
             held_grp++;
             young += SPK;
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
 
   // ONE loop over the k-steps of all tiles of this block (a single k-step body keeps the register allocation simple)
   int buf = 0, ks = 0;
-  bool has_next = it + 1 < it_end;
+  bool has_next = it_next < cnt;
   while (true) {
     // this wave's copies of stage `buf` have landed (the `young` operations behind them may still be in flight);
     // after the barrier every wave's have, and every wave is done reading buffer buf^1
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
     pk_barrier();
     if (ks + 1 == c_nk && has_next) {
       // last k-step of this tile: the staging state moves on to the next tile, whose stage 0 is issued here
-      setup(it + 1, c_par ^ 1);
+      setup(it_next, c_par ^ 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       pk_barrier();
       retap();
@@ -370,8 +384,10 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
     for (int b = 0; b < FP; b++) hoff[b] = sOut[c_par * PT + wpI * WP + b * 16 + fr];
     held_grp = 0;
     if (!has_next) break;
-    it++;
-    has_next = it + 1 < it_end;
+    it = it_next;
+    advance(n_round, n_j);
+    it_next = tile_of(n_round, n_j);
+    has_next = it_next < cnt;
     ks = 0;
     c_cob = s_cob;
     c_nk = s_nk;
@@ -402,8 +418,9 @@ int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s) {
   if (!persist_enabled()) return -1;
   if (p.raw || p.stats != nullptr || (WT != 128 && WT != 64) || p.act == MT_ACT_TANH) return -1;
   const int cus = 256;
-  const int bpc = 2;
-  if (total <= cus * bpc) return -1;
+  const int bpc = WT == 128 ? 2 : 3;
+  const int nb = cus * bpc;
+  if (total < 2 * nb) return -1;      // (fewer than two tiles per block: nothing to pipeline across)
   unsigned long long w_total = 0;
   for (int i = 0; i < p.nphase; i++) {
     if (p.ph[i].ntaps < 1 || p.ph[i].M >= (1 << 24)) return -1;
@@ -414,15 +431,19 @@ int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s) {
   for (int i = 0; i < p.nphase; i++)
     if (p.ph[i].y_off != 0) return -1;
   if (w_total >= 0x7f000000ull || y_total >= 0x7f000000ull || p.x_bytes >= 0xf0000000u || p.cpc < 1 ||
-      p.Co > MT_PERSIST_MAX_CO - 8)
+      p.Co > persist_max_co(WT) - 8)
     return -1;
-  const int nb = cus * bpc;
-  static const int aux = getenv("MT_PK_STORE_AUX") ? atoi(getenv("MT_PK_STORE_AUX")) : 0;
+  static const int aux = getenv("MT_PK_STORE_AUX") ? atoi(getenv("MT_PK_STORE_AUX")) : 2;
+  // tiles of one pixel tile that are consecutive in the launch's tile order: its weight tiles, times its phases
+  int grp = ((p.CoRows + WT - 1) / WT) * (p.interleave ? p.nphase : 1);
+  grp = grp < 1 ? 1 : (grp > 16 ? 16 : grp);
+  // ... but never so large that blocks stay without work: at least two groups per block
+  while (grp > 1 && total / grp < 2 * nb) grp = (grp + 1) / 2;
   const unsigned wb = (unsigned)w_total, yb = (unsigned)y_total;
-  if (WT == 128 && aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 2>), dim3(nb), dim3(256), 0, s, p, total, wb, yb);
-  else if (WT == 128) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 0>), dim3(nb), dim3(256), 0, s, p, total, wb, yb);
-  else if (aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<64, 2, 2>), dim3(nb), dim3(256), 0, s, p, total, wb, yb);
-  else hipLaunchKernelGGL((igemm_persist_kernel<64, 2, 0>), dim3(nb), dim3(256), 0, s, p, total, wb, yb);
+  if (WT == 128 && aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 2>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
+  else if (WT == 128) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 0>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
+  else if (aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<64, 3, 2>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
+  else hipLaunchKernelGGL((igemm_persist_kernel<64, 3, 0>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_persist_launches, 1, __ATOMIC_RELAXED);
   return 0;

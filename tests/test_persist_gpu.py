@@ -1,6 +1,7 @@
 """The persistent gather-GEMM (csrc/conv_persist_kernel.hip) against the per-tile kernel it replaces -- bit for bit:
 both accumulate the same MFMA fragments in the same order -- and against the fp32 CPU reference of the op.
-Shapes have > 512 tiles of 128 pixels (the dispatcher's condition), ragged pixel counts, partial channel tiles,
+Shapes have at least two 128-pixel tiles per resident workgroup (the dispatcher's condition: 1024 tiles for more
+than 64 output channels, 1536 up to 64), ragged pixel counts, partial channel tiles,
 several sub-pixel phases (stride-2 data gradient, transposed convolution) and short reductions (1-2 k-steps)."""
 import pytest
 import torch
@@ -16,14 +17,14 @@ def _lib():
 
 CASES = [
     # name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act
-    ("k3s1_64_128", "conv", 8, 64, 128, 128, 128, 3, 1, 1, "reflect", True, "relu"),
+    ("k3s1_64_128", "conv", 12, 64, 128, 128, 128, 3, 1, 1, "reflect", True, "relu"),
     ("k3s1_ragged_co192", "conv", 3, 40, 150, 151, 192, 3, 1, 1, "reflect", True, "lrelu"),
-    ("k3s1_co64_zero", "conv", 5, 24, 131, 127, 64, 3, 1, 1, "zero", False, None),
+    ("k3s1_co64_zero", "conv", 12, 24, 131, 127, 64, 3, 1, 1, "zero", False, None),
     ("k3s2_dgrad_phases", "conv", 4, 64, 260, 258, 128, 3, 2, 1, "reflect", True, None),
-    ("k4s2_zero_msd", "conv", 5, 8, 256, 256, 64, 4, 2, 1, "zero", False, "lrelu"),
-    ("k1_short_k", "conv", 6, 64, 120, 121, 128, 1, 1, 0, "zero", True, None),
-    ("k7_stem", "conv", 4, 3, 160, 160, 64, 7, 1, 3, "reflect", True, "lrelu"),
-    ("convT_128_64", "convT", 4, 128, 96, 97, 64, 3, 2, 1, "zero", True, None),
+    ("k4s2_zero_msd", "conv", 12, 8, 256, 256, 64, 4, 2, 1, "zero", False, "lrelu"),
+    ("k1_short_k", "conv", 10, 64, 120, 121, 128, 1, 1, 0, "zero", True, None),
+    ("k7_stem", "conv", 8, 3, 160, 160, 64, 7, 1, 3, "reflect", True, "lrelu"),
+    ("convT_128_64", "convT", 6, 128, 96, 97, 64, 3, 2, 1, "zero", True, None),
     ("convT_64_128", "convT", 6, 64, 80, 80, 128, 3, 2, 1, "zero", False, None),
 ]
 
