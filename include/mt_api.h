@@ -113,6 +113,14 @@ size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
  * the parameter's .grad and skip a separate accumulation pass). */
 int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
+/* The same in two halves (mt_conv_bwd_weight = partial + finish on one stream): `partial` runs the bias gradient (if
+ * dbias != NULL) and the split GEMM into fp32 slabs in ws and reports their number; `finish` is the streaming sum of
+ * the slabs into dw.  A caller may issue `finish` on ANOTHER stream (after an event recorded behind `partial`) so that
+ * it runs beside the next layer's GEMMs; ws must stay untouched until it has run. */
+int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, const void* dy, float* dbias, void* ws,
+                               size_t ws_bytes, int accumulate, int want_dw, int* nslabs, mt_stream_t s);
+int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate,
+                              mt_stream_t s);
 
 /* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
 int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,

@@ -536,82 +536,107 @@ static int wgrad_pixels(const mt_conv_desc* d) {
 extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
   int ns, mc;
   wgrad_split(d, wgrad_pixels(d), &ns, &mc);
-  // split slabs of the weight gradient; reused (stream-ordered, after the unpack) for the bias-gradient partials
+  // split slabs of the weight gradient; the bias-gradient partials use the same bytes BEFORE them (stream order)
   const size_t slabs = (size_t)ns * mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
   const size_t bias = mt_colsum_ws_bytes(mt_padc(d->Co));
   return slabs > bias ? slabs : bias;
 }
 
-extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
-                                  void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
+// The weight gradient in two halves, so that a caller may run the second one (a pure streaming reduction of the
+// split slabs) on another stream beside the next layer's GEMMs:
+//   partial: [bias gradient, if asked for] then the split GEMM -> fp32 slabs in ws; *nslabs = how many
+//   finish:  dw (+)= sum of the slabs, reference layout
+// mt_conv_bwd_weight = partial + finish on one stream.
+static int bwd_weight_unpack_params(const mt_conv_desc* d, PackParams* u) {
+  memset(u, 0, sizeof(*u));
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  if (mt_pointwise_small(d)) {
+    u->kW = 1; u->ntaps = 1; u->R = d->Co; u->C = d->Ci; u->Cp = Cip;
+    if (d->transposed) { u->sr = 1; u->sc = d->Co; } else { u->sr = d->Ci; u->sc = 1; }
+    return 0;
+  }
+  u->kW = d->kw; u->ntaps = K2;
+  for (int a = 0; a < d->kh; a++)
+    for (int b = 0; b < d->kw; b++) { u->kh[a * d->kw + b] = (short)a; u->kw[a * d->kw + b] = (short)b; }
+  if (!d->transposed) { u->R = d->Co; u->C = d->Ci; u->Cp = Cip; u->sr = (long)d->Ci * K2; u->sc = K2; }
+  else { u->R = d->Ci; u->C = d->Co; u->Cp = Cop; u->sr = (long)d->Co * K2; u->sc = K2; }
+  return 0;
+}
+
+extern "C" int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, const void* dy, float* dbias, void* ws,
+                                          size_t ws_bytes, int accumulate, int want_dw, int* nslabs, mt_stream_t st) {
   if (check_desc(d)) return 1;
   hipStream_t s = (hipStream_t)st;
   MT_CHECK(ws != nullptr && ws_bytes >= mt_conv_bwd_weight_ws_bytes(d), "conv_bwd_weight: workspace too small");
+  MT_CHECK(nslabs != nullptr, "conv_bwd_weight_partial: nslabs is NULL");
+  *nslabs = 0;
   int Ho, Wo;
   mt_conv_out_hw(d, &Ho, &Wo);
   const int sz = esz(d->dtype), V = vec(d->dtype);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  // the bias gradient first: its partials use the workspace before the slabs do (stream order)
+  if (dbias != nullptr) {
+    const long npix = mt_pointwise_small(d) ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
+    if (mt_launch_colsum(d->dtype, dy, dbias, npix, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
+  }
+  if (!want_dw) return 0;
   if (mt_pointwise_small(d)) {
-    // streaming outer-product reduction into fp32 [Cop][Cip], then the generic unpack (rows = co)
-    if (dw != nullptr) {
-      // one fp32 slab [Cop][Cip] per block (no atomics, nothing to zero); the unpack adds the slabs in index order
-      const long slab = (long)Cop * Cip;
-      int nslabs = 0;
-      const int max_slabs = (int)min((size_t)1024, ws_bytes / (slab * sizeof(float)));
-      if (mt_pw_bwd_weight(d, x, dy, (float*)ws, (long)d->N * d->H * d->W, max_slabs, &nslabs, s)) {
-        mt_set_error("conv_bwd_weight: thin 1x1 weight gradient could not be launched");
-        return 2;
-      }
-      PackParams u;
-      memset(&u, 0, sizeof(u));
-      u.kW = 1; u.ntaps = 1; u.R = d->Co; u.C = d->Ci; u.Cp = Cip;
-      if (d->transposed) { u.sr = 1; u.sc = d->Co; } else { u.sr = d->Ci; u.sc = 1; }
-      if (mt_launch_unpack((const float*)ws, dw, u, nslabs, slab, accumulate, s)) return 2;
-    }
-    if (dbias != nullptr) {
-      if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
+    // streaming outer-product reduction: one fp32 slab [Cop][Cip] per block (no atomics, nothing to zero); the
+    // unpack adds the slabs in index order
+    const long slab = (long)Cop * Cip;
+    const int max_slabs = (int)min((size_t)1024, ws_bytes / (slab * sizeof(float)));
+    if (mt_pw_bwd_weight(d, x, dy, (float*)ws, (long)d->N * d->H * d->W, max_slabs, nslabs, s)) {
+      mt_set_error("conv_bwd_weight: thin 1x1 weight gradient could not be launched");
+      return 2;
     }
     return 0;
   }
   WgradParams p;
   memset(&p, 0, sizeof(p));
-  PackParams u;
-  memset(&u, 0, sizeof(u));
   p.out = (float*)ws;
   p.N = d->N; p.is = d->stride; p.ntaps = K2;
-  u.kW = d->kw; u.ntaps = K2;
   for (int a = 0; a < d->kh; a++)
     for (int b = 0; b < d->kw; b++) {
       const int t = a * d->kw + b;
       p.dh[t] = (short)(a - d->pad); p.dw[t] = (short)(b - d->pad);
-      u.kh[t] = (short)a; u.kw[t] = (short)b;
     }
   if (!d->transposed) {
     // dW[co][kh][kw][ci] = sum dy[n,ho,wo,co] * x[n, pad(ho*s-p+kh), pad(wo*s-p+kw), ci]
     p.a = (const char*)dy; p.Cab = Cop * sz; p.CaRows = Cop; p.Ho = Ho; p.Wo = Wo;
     p.b = (const char*)x; p.Hi = d->H; p.Wi = d->W; p.Cbb = Cip * sz; p.cpc = Cip / V;
     p.pad_mode = d->pad_mode;
-    u.R = d->Co; u.C = d->Ci; u.Cp = Cip; u.sr = (long)d->Ci * K2; u.sc = K2;
   } else {
     // dW[ci][co][kh][kw] = sum x[n,hi,wi,ci] * dy[n, hi*s-p+kh, wi*s-p+kw, co]  (zero outside)
     p.a = (const char*)x; p.Cab = Cip * sz; p.CaRows = Cip; p.Ho = d->H; p.Wo = d->W;
     p.b = (const char*)dy; p.Hi = Ho; p.Wi = Wo; p.Cbb = Cop * sz; p.cpc = Cop / V;
     p.pad_mode = MT_PAD_ZERO;
-    u.R = d->Ci; u.C = d->Co; u.Cp = Cop; u.sr = (long)d->Co * K2; u.sc = K2;
   }
   p.M = d->N * p.Ho * p.Wo;
   p.nchunks = p.ntaps * p.cpc;
-  const int ncols = p.nchunks * V;
   int nsplit;
   bool pipe;
   wgrad_split(d, p.M, &nsplit, &p.mchunk, &pipe);
   p.ntiles = pipe ? -1 : 0;       // tells mt_launch_wgrad which tiling the split was made for
-  if (dw != nullptr) {
-    if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
-    if (mt_launch_unpack((const float*)ws, dw, u, nsplit, (long)p.CaRows * ncols, accumulate, s)) return 2;
-  }
-  if (dbias != nullptr) {
-    if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * Ho * Wo, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
-  }
+  if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
+  *nslabs = nsplit;
   return 0;
+}
+
+extern "C" int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate,
+                                         mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  MT_CHECK(ws != nullptr && dw != nullptr && nslabs > 0, "conv_bwd_weight_finish: nothing to reduce");
+  PackParams u;
+  bwd_weight_unpack_params(d, &u);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  const long slab = mt_pointwise_small(d) ? (long)Cop * Cip : (long)Cop * Cip * K2;
+  return mt_launch_unpack((const float*)ws, dw, u, nslabs, slab, accumulate, (hipStream_t)st) ? 2 : 0;
+}
+
+extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                  void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
+  int nslabs = 0;
+  const int rc = mt_conv_bwd_weight_partial(d, x, dy, dbias, ws, ws_bytes, accumulate, dw != nullptr, &nslabs, st);
+  if (rc) return rc;
+  return dw != nullptr ? mt_conv_bwd_weight_finish(d, ws, nslabs, dw, accumulate, st) : 0;
 }
