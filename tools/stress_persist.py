@@ -18,6 +18,31 @@ SHAPES = [  # kind, N, Ci, H, W, Co, k, stride, pad_mode, bias, act
     ("conv", 16, 5, 256, 256, 64, 4, 2, "reflect", True, None),
 ]
 bad = 0
+# data gradient of a reflect-padded stride-1 layer: interior (persistent, zero padding) + ring GEMM + fold
+for (N, Ci, H, Co) in ((8, 64, 128, 128), (12, 64, 128, 128)):
+    w = (torch.randn(Co, Ci, 3, 3, device=dev) * (Ci * 9) ** -0.5).requires_grad_(False)
+    n0 = lib.mt_kernel_variant_launches(0)
+    mism = 0
+    for it in range(max(iters // 3, 1)):
+        x0 = ops.canon(torch.randn(N, Ci, H, H, device=dev))
+        gy = None
+        outs = []
+        for on in (1, 0):
+            lib.mt_kernel_variant_enable(0, on)
+            x = x0.detach().requires_grad_()
+            y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect", act="relu")
+            if gy is None:
+                gy = ops.canon(torch.randn_like(y.float())).detach()
+            y.backward(gy)
+            outs.append(x.grad.detach())
+        if not torch.equal(outs[0], outs[1]):
+            mism += 1
+            d = (outs[0].float() - outs[1].float()).abs()
+            print(f"  MISMATCH dgrad it {it}: {int((d > 0).sum())} elements differ, max {d.max().item():.3e}", flush=True)
+    lib.mt_kernel_variant_enable(0, 1)
+    print(f"dgrad N{N} {Ci}->{Co} {H}x{H}: {max(iters // 3, 1)} iterations, {lib.mt_kernel_variant_launches(0) - n0} persistent launches, "
+          f"{mism} mismatches", flush=True)
+    bad += mism
 for kind, N, Ci, H, W, Co, k, st, pm, bias, act in SHAPES:
     w = torch.randn(*((Ci, Co, k, k) if kind == "convT" else (Co, Ci, k, k)), device=dev) * (Ci * k * k) ** -0.5
     b = torch.randn(Co, device=dev) * 0.1 if bias else None
