@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmt_hip.so")
+if os.environ.get("MT_LIB_PATH"):      # development only: A/B a differently built library (tools/ab_env.sh, tools/diag_build.sh)
+    LIB_PATH = os.path.abspath(os.environ["MT_LIB_PATH"])
 
 MT_F32, MT_BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
