@@ -63,7 +63,8 @@ typedef struct mt_conv_desc {
 const char* mt_last_error(void);
 int mt_version(void);
 /* launches routed so far to a kernel variant the dispatcher chooses by problem size (tests assert that a shape class
- * really exercised the variant it is meant to cover): which = 0 persistent gather-GEMM (conv_persist_kernel.hip) */
+ * really exercised the variant it is meant to cover): which = 0 persistent gather-GEMM (conv_persist_kernel.hip),
+ * 1 direct 7x7 stem forward (stem_kernel.hip; same values up to fp32 summation order) */
 long mt_kernel_variant_launches(int which);
 /* switch such a variant off / on again (tests compare it bit for bit with the kernel it replaces; both are
  * results-identical by construction); returns the previous setting.  MT_IGEMM_PERSIST=0 in the environment disables

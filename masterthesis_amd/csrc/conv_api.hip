@@ -365,6 +365,10 @@ extern "C" int mt_conv_fwd_ex(const mt_conv_desc* d, const void* x, const void* 
   mt_conv_out_hw(d, &Ho, &Wo);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
   if (mt_pointwise_small(d)) return mt_pw_fwd(d, x, pack_fwd, bias, y, (long)d->N * d->H * d->W, s);
+  if (!d->transposed) {
+    const int r = mt_launch_stem_fwd(d, x, pack_fwd, bias, y, nullptr, s);     // the 7x7 stem: direct kernel
+    if (r >= 0) return r;
+  }
   if (!d->transposed)
     return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, nullptr, ws,
                        ws_bytes);
@@ -401,6 +405,10 @@ extern "C" int mt_conv_fwd_stats(const mt_conv_desc* d, const void* x, const voi
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
   MT_CHECK(stats_fusable(d), "conv_fwd_stats: this shape has no fused statistics epilogue (mt_conv_fwd_stats_fused() == 0): "
                              "run mt_conv_fwd followed by mt_nc_stats");
+  {
+    const int r = mt_launch_stem_fwd(d, x, pack_fwd, bias, y, stats, s);
+    if (r >= 0) return r;
+  }
   return gather_form(d, x, d->H, d->W, Cip, pack_fwd, bias, d->Co, y, Ho, Wo, Cop, d->pad_mode, d->act, s, stats);
 }
 

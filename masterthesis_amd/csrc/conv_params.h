@@ -112,8 +112,11 @@ size_t mt_colsum_ws_bytes(int Cp);
 int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, int C, int accumulate, void* ws,
                      size_t ws_bytes, hipStream_t s);
 
+// direct 7x7 stem forward (stem_kernel.hip): 0 launched, 2 error, -1 not its shape
+int mt_launch_stem_fwd(const mt_conv_desc* d, const void* x, const void* pack, const float* bias, void* y, float* stats,
+                       hipStream_t s);
+
 // thin 1x1 convolutions (pointwise_kernels.hip); the launchers return -1 if no instantiation matches
-struct mt_conv_desc;
 bool mt_pointwise_small(const mt_conv_desc* d);
 int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const float* bias, void* y, long npix, hipStream_t s);
 int mt_pw_bwd_data(const mt_conv_desc* d, const void* dy, const void* wpack, void* dx, long npix, hipStream_t s);

@@ -405,8 +405,13 @@ static int persist_enabled() {
   if (g_persist_on < 0) g_persist_on = getenv("MT_IGEMM_PERSIST") ? (atoi(getenv("MT_IGEMM_PERSIST")) != 0) : 1;
   return g_persist_on;
 }
-extern "C" long mt_kernel_variant_launches(int which) { return which == 0 ? g_persist_launches : -1; }
+long mt_stem_launches();            // stem_kernel.hip
+int mt_stem_enable(int on);
+extern "C" long mt_kernel_variant_launches(int which) {
+  return which == 0 ? g_persist_launches : (which == 1 ? mt_stem_launches() : -1);
+}
 extern "C" int mt_kernel_variant_enable(int which, int enable) {
+  if (which == 1) return mt_stem_enable(enable != 0);
   if (which != 0) return -1;
   const int prev = persist_enabled();
   g_persist_on = enable != 0;

@@ -54,6 +54,7 @@ def test_persistent_matches_per_tile_kernel(case, hip_device):
     ops.set_compute_dtype(torch.bfloat16)
     lib = _lib()
     prev = lib.mt_kernel_variant_enable(0, 1)
+    prev_stem = lib.mt_kernel_variant_enable(1, 0)      # (the 7x7 case is about the gather-GEMM pair, not the direct stem kernel)
     try:
         n0 = lib.mt_kernel_variant_launches(0)
         (x, w, b, gy), (y1, dx1) = _run(ops, case, hip_device)
@@ -64,6 +65,7 @@ def test_persistent_matches_per_tile_kernel(case, hip_device):
         assert lib.mt_kernel_variant_launches(0) == n1
     finally:
         lib.mt_kernel_variant_enable(0, prev)
+        lib.mt_kernel_variant_enable(1, prev_stem)
     assert torch.equal(y1, y0), f"forward differs: max {(y1 - y0).abs().max().item():.3e}"
     assert torch.equal(dx1, dx0), f"data gradient differs: max {(dx1 - dx0).abs().max().item():.3e}"
     # ... and both against the op's fp32 reference
