@@ -542,6 +542,10 @@ static int wgrad_pixels(const mt_conv_desc* d) {
 }
 
 extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
+  if (mt_stem_wgrad_ok(d)) {                 // direct 7x7 stem kernel: one slab per workgroup
+    const size_t a = mt_stem_wgrad_ws_bytes(d), b = mt_colsum_ws_bytes(mt_padc(d->Co));
+    return a > b ? a : b;
+  }
   int ns, mc;
   wgrad_split(d, wgrad_pixels(d), &ns, &mc);
   // split slabs of the weight gradient; the bias-gradient partials use the same bytes BEFORE them (stream order)
@@ -588,6 +592,7 @@ extern "C" int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, 
     if (mt_launch_colsum(d->dtype, dy, dbias, npix, Cop, d->Co, accumulate, ws, ws_bytes, s)) return 2;
   }
   if (!want_dw) return 0;
+  if (mt_stem_wgrad_ok(d)) return mt_launch_stem_wgrad(d, x, dy, ws, nslabs, s) ? 2 : 0;
   if (mt_pointwise_small(d)) {
     // streaming outer-product reduction: one fp32 slab [Cop][Cip] per block (no atomics, nothing to zero); the
     // unpack adds the slabs in index order
@@ -634,6 +639,7 @@ extern "C" int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, 
                                          mt_stream_t st) {
   if (check_desc(d)) return 1;
   MT_CHECK(ws != nullptr && dw != nullptr && nslabs > 0, "conv_bwd_weight_finish: nothing to reduce");
+  if (mt_stem_wgrad_ok(d)) return mt_launch_stem_wgrad_reduce(d, ws, nslabs, dw, accumulate, (hipStream_t)st) ? 2 : 0;
   PackParams u;
   bwd_weight_unpack_params(d, &u);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;

@@ -116,6 +116,12 @@ int mt_launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp, in
 int mt_launch_stem_fwd(const mt_conv_desc* d, const void* x, const void* pack, const float* bias, void* y, float* stats,
                        hipStream_t s);
 
+// ... and its weight gradient: slabs [nslabs][64][224] into ws, then the reduce into the reference layout
+bool mt_stem_wgrad_ok(const mt_conv_desc* d);
+size_t mt_stem_wgrad_ws_bytes(const mt_conv_desc* d);
+int mt_launch_stem_wgrad(const mt_conv_desc* d, const void* x, const void* dy, void* ws, int* nslabs, hipStream_t s);
+int mt_launch_stem_wgrad_reduce(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate, hipStream_t s);
+
 // thin 1x1 convolutions (pointwise_kernels.hip); the launchers return -1 if no instantiation matches
 bool mt_pointwise_small(const mt_conv_desc* d);
 int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const float* bias, void* y, long npix, hipStream_t s);

@@ -247,3 +247,238 @@ int mt_launch_stem_fwd(const mt_conv_desc* d, const void* x, const void* pack, c
   __atomic_fetch_add(&g_stem_launches, 1, __ATOMIC_RELAXED);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Direct 7x7 stem weight gradient (bf16):  dW[co][ch][dh][dw] = sum_{n,y,x} dy[n,y,x,co] * xpad[n, y+dh-3, x+dw-3, ch].
+// The gather form streams 49 sixteen-byte pieces of x per pixel (205 us at N = 16, 256x256 for 140 MB of operands);
+// here a workgroup walks 8x32-pixel tiles, keeps the tile of dy ([256 px][64 co], 32 KiB) and the 14x39 input patch
+// (8 bytes per pixel) in LDS and reduces over pixels with the MFMA K dimension = 32 consecutive pixels of a tile row:
+//   D[j][co] += sum_px P[px][j] * dy[px][co],   j = (dh, [dw, ch]) -- per filter row dh a 32-wide run of the patch
+// Both operands are pixel-major, so the fragments come from the transposing LDS read ds_read_b64_tr_b16; for the patch
+// the "matrix row" of pixel x is the 64 bytes starting at that pixel (rows overlap: pitch 8 bytes).
+// The 7 x 2 (filter row, run half) output fragments are split over the 4 waves (4, 4, 3, 3), each with all 4 cout
+// fragments.  Every workgroup accumulates ONE partial dW over all its tiles and writes it as a slab
+// [64 co][224 j] fp32; stem_wgrad_reduce_kernel adds the slabs in index order (reproducible) into the reference layout.
+constexpr int SW_TH = 8, SW_TW = 32;                   // pixel tile
+constexpr int SW_PH = SW_TH + 6, SW_PP = 40;           // patch rows, patch row pitch in pixels (39 read)
+constexpr int SW_SLAB = 64 * 224;                      // floats per slab
+
+struct StemWgradParams {
+  const char* x;        // NHWC [N][H][W][8] bf16
+  const char* dy;       // NHWC [N][H][W][64] bf16
+  float* slabs;         // [gridDim.x][64][224]
+  int N, H, W;
+  int pad_mode;
+  int tiles_x, tiles_y, total;
+  unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParams p) {
+  constexpr unsigned OOB = 0x80000000u;
+  // ONE shared array (LDS-DMA target): 2 dy tiles, then 2 patches
+  __shared__ u32x4 smem[(2 * 256 * 128 + 2 * SW_PH * SW_PP * 8) / 16];
+  char* const sDy = reinterpret_cast<char*>(smem);                       // [2][256 px][128 B], 32-byte slots XOR (row>>3)&3
+  char* const sP = sDy + 2 * 256 * 128;                                   // [2][14][40 px][8 B]
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef __attribute__((address_space(3))) s16x4* lds_s4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+  auto tile_coords = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % p.tiles_x;
+    const int t2 = tile / p.tiles_x;
+    n = t2 / p.tiles_y;
+    y0 = (t2 - n * p.tiles_y) * SW_TH;
+    x0 = tx * SW_TW;
+  };
+  // dy tile -> LDS buffer `buf` by LDS-DMA: wave w, instruction i covers tile rows (pixels) 8*(w + 4 i) .. +7, a lane
+  // one 16-byte chunk: LDS position (row, pos) receives logical chunk ((pos>>1) ^ key) << 1 | (pos & 1), key = (row>>3)&3
+  auto issue_dy = [&](int buf, int n, int y0, int x0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int blk = wvu + 4 * i;                    // 8-pixel block of the tile: pixels 8 blk .. 8 blk + 7
+      const int px = blk * 8 + (lane >> 3);           // tile pixel = ty * 32 + tx
+      const int pos = lane & 7;
+      const int key = blk & 3;
+      const int chunk = (((pos >> 1) ^ key) << 1) | (pos & 1);
+      const int y = y0 + (px >> 5), xx = x0 + (px & 31);
+      const bool ok = y < p.H && xx < p.W;
+      const unsigned o = ok ? (unsigned)((n * p.H + y) * p.W + xx) * 128u + (unsigned)chunk * 16u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sDy + buf * 256 * 128 + blk * 1024), 16, o, 0, 0, 0);
+    }
+  };
+  // patch pixels of this thread: idx = tid + 256 j (< 14 * 39)
+  auto patch_load = [&](int n, int y0, int x0, u32x2* v) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int idx = tid + 256 * j;
+      const int pr = idx / 39, pc = idx - pr * 39;
+      int r = y0 + pr - 3, c = x0 + pc - 3;
+      bool ok = idx < SW_PH * 39;
+      if (p.pad_mode == MT_PAD_REFLECT) {
+        r = r < 0 ? -r : r;
+        r = r >= p.H ? 2 * (p.H - 1) - r : r;
+        c = c < 0 ? -c : c;
+        c = c >= p.W ? 2 * (p.W - 1) - c : c;
+      }
+      ok = ok && (unsigned)r < (unsigned)p.H && (unsigned)c < (unsigned)p.W;
+      const unsigned o = ok ? (unsigned)((n * p.H + r) * p.W + c) * 16u : OOB;
+      v[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsx, o, 0, 0));
+    }
+  };
+  auto patch_store = [&](int buf, const u32x2* v) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int idx = tid + 256 * j;
+      if (idx < SW_PH * 39) {
+        const int pr = idx / 39, pc = idx - pr * 39;
+        *reinterpret_cast<u32x2*>(sP + ((buf * SW_PH + pr) * SW_PP + pc) * 8) = v[j];
+      }
+    }
+  };
+
+  // persistent schedule (as in the forward kernel)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nslot = ((int)gridDim.x - xcd + 7) >> 3;
+  const int tq = p.total >> 3, tr = p.total & 7;
+  const int lo = xcd * tq + (xcd < tr ? xcd : tr);
+  const int cnt = tq + (xcd < tr ? 1 : 0);
+  int it = slot;
+
+  f32x4 acc[4][4];        // [cout fragment][this wave's (dh, half) fragments q = wv, wv+4, wv+8, wv+12]
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc[a][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (it < cnt) {
+    int n, y0, x0;
+    tile_coords(lo + it, n, y0, x0);
+    u32x2 pv[3];
+    issue_dy(0, n, y0, x0);
+    patch_load(n, y0, x0, pv);
+    patch_store(0, pv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+      const int it_next = it + nslot;
+      const bool has_next = it_next < cnt;
+      if (has_next) {
+        tile_coords(lo + it_next, n, y0, x0);
+        issue_dy(buf ^ 1, n, y0, x0);
+        patch_load(n, y0, x0, pv);
+      }
+      const char* dyb = sDy + buf * 256 * 128;
+      const char* pb = sP + buf * SW_PH * SW_PP * 8;
+#pragma unroll
+      for (int r = 0; r < SW_TH; r++) {               // k-step = the 32 pixels of tile row r
+        bf16x8 af[4], bf[4];
+        const int prow = r * 32 + 8 * g + qq;         // (key of the dy swizzle = (prow >> 3) & 3 = g)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const char* pa = dyb + prow * 128 + ((a ^ g) * 32) + pp * 8;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(pa));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(pa + 4 * 128));
+          af[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int q = wv + 4 * s;                   // (dh, half) fragment of this wave; q >= 14: none
+          const int dh = q >> 1, half = q & 1;
+          const char* pq = pb + ((r + (dh < 7 ? dh : 0)) * SW_PP + 8 * g + qq) * 8 + half * 32 + pp * 8;
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(pq));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(pq + 32));
+          bf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (wv + 4 * s >= 14) continue;             // (wave-uniform)
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            acc[a][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s], af[a], acc[a][s], 0, 0, 0);
+        }
+      }
+      if (!has_next) break;
+      patch_store(buf ^ 1, pv);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();       // next tile landed; everyone is done with buffer `buf`
+      buf ^= 1;
+      it = it_next;
+    }
+  }
+  // slab of this workgroup (zeros if it had no tile): the MFMAs ran with the patch as the row operand, so a lane holds
+  // D[j = 16 q + 4 fg + e][co = 16 a + fr]: 4 consecutive j of one cout row
+  float* slab = p.slabs + (size_t)blockIdx.x * SW_SLAB;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int q = wv + 4 * s;
+    if (q >= 14) continue;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+      *reinterpret_cast<f32x4*>(slab + (size_t)(16 * a + fr) * 224 + 16 * q + 4 * fg) = acc[a][s];
+  }
+}
+
+// dw[co][ch][dh][dw] (+)= sum_b slab[b][co][dh*32 + dw*4 + ch], slabs added in index order
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nslabs, int Ci,
+                                         int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over (co, dh, dw, ch): ch fastest = slab order
+  if (i >= 64 * 7 * 7 * 4) return;
+  const int ch = i & 3, dwi = (i >> 2) % 7, dh = (i / 28) % 7, co = i / 196;
+  if (ch >= Ci) return;
+  const float* s = slabs + (size_t)co * 224 + dh * 32 + dwi * 4 + ch;
+  float a = 0.f;
+  int k = 0;
+  for (; k + 4 <= nslabs; k += 4) {
+    const float v0 = s[(size_t)k * SW_SLAB], v1 = s[(size_t)(k + 1) * SW_SLAB];
+    const float v2 = s[(size_t)(k + 2) * SW_SLAB], v3 = s[(size_t)(k + 3) * SW_SLAB];
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; k < nslabs; k++) a += s[(size_t)k * SW_SLAB];
+  float* o = dw + (((size_t)co * Ci + ch) * 7 + dh) * 7 + dwi;
+  *o = accumulate ? *o + a : a;
+}
+
+bool mt_stem_wgrad_ok(const mt_conv_desc* d) {
+  mt_stem_enable(-1);
+  if (!g_stem_on) return false;
+  if (d->dtype != MT_BF16 || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->Ci > 4 ||
+      d->Co != 64 || d->H < 8 || d->W < 8)
+    return false;
+  return (unsigned long long)d->N * d->H * d->W * 128ull < 0x7f000000ull;
+}
+static int stem_wgrad_blocks(const mt_conv_desc* d) {
+  const int total = d->N * cdiv(d->W, SW_TW) * cdiv(d->H, SW_TH);
+  return total < 512 ? total : 512;
+}
+size_t mt_stem_wgrad_ws_bytes(const mt_conv_desc* d) { return (size_t)stem_wgrad_blocks(d) * SW_SLAB * sizeof(float); }
+
+// slabs -> ws; *nslabs = their number
+int mt_launch_stem_wgrad(const mt_conv_desc* d, const void* x, const void* dy, void* ws, int* nslabs, hipStream_t s) {
+  StemWgradParams p;
+  p.x = (const char*)x; p.dy = (const char*)dy; p.slabs = (float*)ws;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.pad_mode = d->pad_mode;
+  p.tiles_x = cdiv(d->W, SW_TW); p.tiles_y = cdiv(d->H, SW_TH);
+  p.total = d->N * p.tiles_x * p.tiles_y;
+  p.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * 16); p.dy_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128);
+  const int nb = stem_wgrad_blocks(d);
+  *nslabs = nb;
+  if (nb <= 0) return 0;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, s, p);
+  MT_LAUNCH_CHECK();
+  __atomic_fetch_add(&g_stem_launches, 1, __ATOMIC_RELAXED);
+  return 0;
+}
+int mt_launch_stem_wgrad_reduce(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(64 * 196, 256)), dim3(256), 0, s, (const float*)ws, dw, nslabs, d->Ci,
+                     accumulate);
+  MT_LAUNCH_CHECK();
+  return 0;
+}

@@ -95,3 +95,52 @@ def test_stem_direct_statistics(shape, hip_device):
     ref_s = torch.stack([y1.sum((2, 3)), (y1 * y1).sum((2, 3))], -1)
     assert torch.allclose(s1, ref_s, rtol=2e-3, atol=2e-2 * (H * W) ** 0.5), (s1 - ref_s).abs().max()
     assert torch.allclose(s1, s0, rtol=5e-3, atol=5e-2 * (H * W) ** 0.5), (s1 - s0).abs().max()
+
+
+WG_CASES = [
+    # name, N, Ci, H, W, pad_mode
+    ("reflect", 2, 3, 64, 64, "reflect"),
+    ("ragged", 3, 3, 40, 53, "reflect"),
+    ("zero", 2, 3, 33, 47, "zero"),
+    ("four_channels", 1, 4, 48, 32, "reflect"),
+    ("bench_size", 4, 3, 256, 256, "reflect"),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_stem_direct_weight_gradient(case, hip_device):
+    """dW of the 7x7 stem: direct kernel vs the gather form vs the fp32 reference (both accumulate in fp32; the
+    operands are bf16-exact, so all three agree to fp32 summation noise)"""
+    from masterthesis_amd import hip_ops as ops, _lib
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = _lib.load()
+    name, N, Ci, H, W, pad_mode = case
+    g = torch.Generator().manual_seed(7 + len(name))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, Ci, 7, 7, generator=g) * (Ci * 49) ** -0.5).bfloat16().float()
+    gy = torch.randn(N, 64, H, W, generator=g).bfloat16().float()
+    xr, wr = x.clone(), w.clone().requires_grad_()
+    xp = F.pad(xr, (3,) * 4, mode="reflect") if pad_mode == "reflect" else F.pad(xr, (3,) * 4)
+    F.conv2d(xp, wr).backward(gy)
+    grads = []
+    prev = lib.mt_kernel_variant_enable(1, 1)
+    try:
+        for on in (1, 0):
+            lib.mt_kernel_variant_enable(1, on)
+            wd = w.to(hip_device).requires_grad_()
+            y = ops.conv2d(x.to(hip_device), wd, None, stride=1, pad=3, pad_mode=pad_mode)
+            n0 = lib.mt_kernel_variant_launches(1)
+            y.backward(gy.to(hip_device))
+            if on:
+                assert lib.mt_kernel_variant_launches(1) == n0 + 1, "the weight gradient was meant to run on the direct kernel"
+            grads.append(wd.grad.float().cpu())
+            # accumulate into an existing gradient (the fused in-place path of the training step)
+            y2 = ops.conv2d(x.to(hip_device), wd, None, stride=1, pad=3, pad_mode=pad_mode)
+            y2.backward(gy.to(hip_device))
+            assert torch.allclose(wd.grad.float().cpu(), 2 * grads[-1], rtol=1e-4, atol=1e-3)
+    finally:
+        lib.mt_kernel_variant_enable(1, prev)
+    ref = wr.grad
+    scale = ref.abs().max().item()
+    for got, what in ((grads[0], "direct"), (grads[1], "gather form")):
+        assert (got - ref).abs().max().item() <= 2e-4 * scale + 1e-3, (what, (got - ref).abs().max().item(), scale)

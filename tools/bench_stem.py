@@ -26,3 +26,22 @@ for N in (16, 32):
             lib.mt_kernel_variant_enable(1, on); r.append(t(f))
         lib.mt_kernel_variant_enable(1, 1)
         print(f"N{N} stats={int(st)}: gather-GEMM {r[0]:.1f} us, direct {r[1]:.1f} us")
+
+for N in (16, 32):
+    x = ops.canon(torch.randn(N, 3, 256, 256, device=dev))
+    w = (torch.randn(64, 3, 7, 7, device=dev) * 0.08).requires_grad_()
+    gy = None
+    r = []
+    for on in (0, 1):
+        lib.mt_kernel_variant_enable(1, on)
+        def fwd():
+            with torch.no_grad(): ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect")
+        def both():
+            w.grad = None
+            y = ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect")
+            y.backward(gy if gy is not None else torch.ones_like(y))
+        y0 = ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect")
+        gy = ops.canon(torch.randn_like(y0.float())).detach()
+        r.append(t(both) - t(fwd))
+    lib.mt_kernel_variant_enable(1, 1)
+    print(f"N{N} weight gradient (backward minus forward, x without gradient): gather form {r[0]:.1f} us, direct {r[1]:.1f} us")
