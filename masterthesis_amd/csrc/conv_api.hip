@@ -445,6 +445,12 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   const size_t padded_b = bwd_data_padded_bytes(d), split_b = bwd_data_split_bytes(d);
   const bool have_ws = ws != nullptr && ws_bytes >= padded_b + split_b;
   void* split_ws = (have_ws && split_b) ? (char*)ws + padded_b : nullptr;
+  if (mt_stem_dgrad_ok(d)) {                 // the 7x7 stem: direct kernel (stem_kernel.hip)
+    if (P == 0) return mt_launch_stem_dgrad(d, dy, pack_bwd, dx, s) ? 2 : 0;
+    MT_CHECK(ws != nullptr && ws_bytes >= padded_b, "conv_bwd_data: workspace too small");
+    if (mt_launch_stem_dgrad(d, dy, pack_bwd, ws, s)) return 2;
+    return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
+  }
   if (P == 0)
     return scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, dx, d->H, d->W, Cip, d->pad, MT_ACT_NONE, s, split_ws,
                         split_b);

@@ -122,6 +122,10 @@ size_t mt_stem_wgrad_ws_bytes(const mt_conv_desc* d);
 int mt_launch_stem_wgrad(const mt_conv_desc* d, const void* x, const void* dy, void* ws, int* nslabs, hipStream_t s);
 int mt_launch_stem_wgrad_reduce(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate, hipStream_t s);
 
+// ... and its data gradient on the padded grid (reflection padding: fold afterwards) or straight into dx (zero padding)
+bool mt_stem_dgrad_ok(const mt_conv_desc* d);
+int mt_launch_stem_dgrad(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* out, hipStream_t s);
+
 // thin 1x1 convolutions (pointwise_kernels.hip); the launchers return -1 if no instantiation matches
 bool mt_pointwise_small(const mt_conv_desc* d);
 int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const float* bias, void* y, long npix, hipStream_t s);

@@ -426,24 +426,32 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
   }
 }
 
-// dw[co][ch][dh][dw] (+)= sum_b slab[b][co][dh*32 + dw*4 + ch], slabs added in index order
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nslabs, int Ci,
-                                         int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over (co, dh, dw, ch): ch fastest = slab order
-  if (i >= 64 * 7 * 7 * 4) return;
-  const int ch = i & 3, dwi = (i >> 2) % 7, dh = (i / 28) % 7, co = i / 196;
-  if (ch >= Ci) return;
-  const float* s = slabs + (size_t)co * 224 + dh * 32 + dwi * 4 + ch;
-  float a = 0.f;
-  int k = 0;
-  for (; k + 4 <= nslabs; k += 4) {
-    const float v0 = s[(size_t)k * SW_SLAB], v1 = s[(size_t)(k + 1) * SW_SLAB];
-    const float v2 = s[(size_t)(k + 2) * SW_SLAB], v3 = s[(size_t)(k + 3) * SW_SLAB];
-    a += v0; a += v1; a += v2; a += v3;
+// dw[co][ch][dh][dw] (+)= sum_b slab[b][co][dh*32 + dw*4 + ch].  One WAVE per 4 consecutive j of a cout row: lane l adds
+// slabs l, l+64, ... in index order, then the fixed xor-shuffle tree of wave_sum (a serial walk over 512 slabs per
+// thread took 44 us -- longer than the gradient kernel itself).  The order is fixed, so the result is reproducible.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                int nslabs, int Ci, int accumulate) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);        // (co, j4): 64 x 56 groups of 4 floats
+  const int lane = threadIdx.x & 63;
+  if (i >= 64 * 56) return;
+  const int co = i / 56, j4 = i - co * 56;
+  const f32x4* s = reinterpret_cast<const f32x4*>(slabs + (size_t)co * 224 + j4 * 4);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < nslabs; k += 64) a += s[(size_t)k * (SW_SLAB / 4)];
+#pragma unroll
+  for (int e = 0; e < 4; e++) a[e] = wave_sum(a[e]);
+  if (lane == 0) {
+    const int j = j4 * 4;                                   // = dh*32 + dw*4 (+ ch = e)
+    const int dh = j >> 5, dwi = (j & 31) >> 2;
+    if (dwi < 7) {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (e < Ci) {
+          float* o = dw + (((size_t)co * Ci + e) * 7 + dh) * 7 + dwi;
+          *o = accumulate ? *o + a[e] : a[e];
+        }
+    }
   }
-  for (; k < nslabs; k++) a += s[(size_t)k * SW_SLAB];
-  float* o = dw + (((size_t)co * Ci + ch) * 7 + dh) * 7 + dwi;
-  *o = accumulate ? *o + a : a;
 }
 
 bool mt_stem_wgrad_ok(const mt_conv_desc* d) {
@@ -456,7 +464,8 @@ bool mt_stem_wgrad_ok(const mt_conv_desc* d) {
 }
 static int stem_wgrad_blocks(const mt_conv_desc* d) {
   const int total = d->N * cdiv(d->W, SW_TW) * cdiv(d->H, SW_TH);
-  return total < 512 ? total : 512;
+  static const int cap = getenv("MT_STEM_WG_BLOCKS") ? atoi(getenv("MT_STEM_WG_BLOCKS")) : 384;   // (256: 54 + 9 us, 384: 43 + 12, 512: 42 + 15 for kernel + reduce)
+  return total < cap ? total : cap;
 }
 size_t mt_stem_wgrad_ws_bytes(const mt_conv_desc* d) { return (size_t)stem_wgrad_blocks(d) * SW_SLAB * sizeof(float); }
 
@@ -477,8 +486,129 @@ int mt_launch_stem_wgrad(const mt_conv_desc* d, const void* x, const void* dy, v
   return 0;
 }
 int mt_launch_stem_wgrad_reduce(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(64 * 196, 256)), dim3(256), 0, s, (const float*)ws, dw, nslabs, d->Ci,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 56 / 4), dim3(256), 0, s, (const float*)ws, dw, nslabs, d->Ci,
                      accumulate);
   MT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Direct 7x7 stem data gradient (bf16): the full correlation of dy with the filter on an output grid G (the padded
+// (H+6)x(W+6) grid for reflection padding -- reflect_fold_kernel adds the border back afterwards -- or the HxW image
+// itself for zero padding):   dxg[py][px][ch] = sum_{dh,dw,co} dy[py+o-dh][px+o-dw][co] * w[co][ch][dh][dw],  o = 0 / 3.
+// As a gather GEMM this is 49 taps x 64 couts = 3136 reduction elements for 3 output channels: dy is re-read 49 times
+// through LDS-DMA (6.4 GB for 134 MB at N = 16, 256x256: 338 us, the L2->LDS peak).  Here the 14x22-pixel patch of dy
+// that an 8x16 output tile needs sits in LDS (16-byte chunks XOR-swizzled by the pixel column), the four weight rows
+// [ch][tap][co] too (25 KiB, straight from the data-gradient pack), and K = (tap, co) runs over the patch:
+//   D[ch][pixel] += W[ch][k] * dy_patch[k][pixel]        (MFMA 16x16x32, rows 4..15 of the weight operand are zero)
+// 3 of 16 MFMA rows carry data -- the kernel is bound by the LDS reads of the patch, not by the matrix pipe.
+constexpr int SD_TH = 8, SD_TW = 16;
+constexpr int SD_PH = SD_TH + 6, SD_PW = SD_TW + 6;     // 14 x 22 pixels of dy
+constexpr int SD_WROW = 49 * 64 * 2;                    // bytes of one weight row [tap][co]
+
+struct StemDgradParams {
+  const char* dy;       // NHWC [N][H][W][64] bf16
+  const char* wpack;    // data-gradient pack [8 rows = ch][49 taps][64 co] bf16
+  char* out;            // NHWC [N][Hg][Wg][8] bf16
+  int N, H, W, Hg, Wg, off;
+  int tiles_x, tiles_y, total;
+  unsigned dy_bytes, out_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const StemDgradParams p) {
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ u32x4 smem[(4 * SD_WROW + SD_PH * SD_PW * 128) / 16];
+  char* const sW = reinterpret_cast<char*>(smem);              // [4 ch][49][64] bf16
+  char* const sP = sW + 4 * SD_WROW;                           // [14][22 px][8 chunks of 16 B, chunk ^ (px & 7)]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < 4 * SD_WROW / 16; i += 256)
+    reinterpret_cast<u32x4*>(sW)[i] = reinterpret_cast<const u32x4*>(p.wpack)[i];     // rows 0..3 of the pack are contiguous
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nslot = ((int)gridDim.x - xcd + 7) >> 3;
+  const int tq = p.total >> 3, tr = p.total & 7;
+  const int lo = xcd * tq + (xcd < tr ? xcd : tr);
+  const int cnt = tq + (xcd < tr ? 1 : 0);
+  const bool arow = fr < 4;                                   // lanes that hold a real weight row
+  const char* wbase = sW + (arow ? fr : 0) * SD_WROW + fg * 16;
+
+  for (int it = slot; it < cnt; it += nslot) {
+    const int tile = lo + it;
+    const int tx = tile % p.tiles_x;
+    const int t2 = tile / p.tiles_x;
+    const int n = t2 / p.tiles_y;
+    const int py0 = (t2 - n * p.tiles_y) * SD_TH, px0 = tx * SD_TW;
+    __syncthreads();                                          // everyone is done with the previous patch (and sW is written)
+    // patch: 14 x 22 pixels x 8 chunks; dy row = py0 + off - 6 + pr, column = px0 + off - 6 + pc (zeros outside dy)
+    for (int i = tid; i < SD_PH * SD_PW * 8; i += 256) {
+      const int ck = i & 7, pix = i >> 3;
+      const int pr = pix / SD_PW, pc = pix - pr * SD_PW;
+      const int y = py0 + p.off - 6 + pr, x = px0 + p.off - 6 + pc;
+      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const unsigned o = ok ? (unsigned)((n * p.H + y) * p.W + x) * 128u + (unsigned)ck * 16u : OOB;
+      const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, o, 0, 0));
+      *reinterpret_cast<u32x4*>(sP + (pix * 8 + (ck ^ (pc & 7))) * 16) = v;
+    }
+    __syncthreads();
+    // this wave: tile rows 2 wv, 2 wv + 1; pixel fragment = the 16 columns of a row
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+    for (int dh = 0; dh < 7; dh++) {
+#pragma unroll
+      for (int dw = 0; dw < 7; dw++) {
+        const int pc = fr + 6 - dw;
+        const char* w = wbase + (dh * 7 + dw) * 128;
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) {
+          u32x4 wf = *reinterpret_cast<const u32x4*>(w + kc * 64);
+          if (!arow) wf = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            const int pr = 2 * wv + b + 6 - dh;
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(sP + ((pr * SD_PW + pc) * 8 + ((kc * 4 + fg) ^ (pc & 7))) * 16);
+            mma_chunk<true>(acc[b], wf, xf);
+          }
+        }
+      }
+    }
+    // lanes fg == 0 hold channels 0..3 of pixel (row, column fr); channels 4..7 of the padded layout are zero
+    if (fg == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int py = py0 + 2 * wv + b, px = px0 + fr;
+        const bool ok = py < p.Hg && px < p.Wg;
+        const u32x4 o = {pack2_bf16(acc[b][0], acc[b][1]), pack2_bf16(acc[b][2], acc[b][3]), 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rso, ok ? (unsigned)((n * p.Hg + py) * p.Wg + px) * 16u : OOB, 0, 0);
+      }
+    }
+  }
+}
+
+bool mt_stem_dgrad_ok(const mt_conv_desc* d) {
+  mt_stem_enable(-1);
+  if (!g_stem_on) return false;
+  if (d->dtype != MT_BF16 || d->transposed || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->Ci > 4 ||
+      d->Co != 64 || d->H < 8 || d->W < 8)
+    return false;
+  return (unsigned long long)d->N * (d->H + 6) * (d->W + 6) * 128ull < 0x7f000000ull;
+}
+// out: the padded grid [N][H+6][W+6][8] (reflection padding; fold it afterwards) or dx itself (zero padding)
+int mt_launch_stem_dgrad(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* out, hipStream_t s) {
+  StemDgradParams p;
+  const bool refl = d->pad_mode == MT_PAD_REFLECT;
+  p.dy = (const char*)dy; p.wpack = (const char*)pack_bwd; p.out = (char*)out;
+  p.N = d->N; p.H = d->H; p.W = d->W;
+  p.Hg = refl ? d->H + 6 : d->H; p.Wg = refl ? d->W + 6 : d->W; p.off = refl ? 0 : 3;
+  p.tiles_x = cdiv(p.Wg, SD_TW); p.tiles_y = cdiv(p.Hg, SD_TH);
+  p.total = d->N * p.tiles_x * p.tiles_y;
+  p.dy_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128); p.out_bytes = (unsigned)((size_t)d->N * p.Hg * p.Wg * 16);
+  if (p.total <= 0) return 0;
+  const int nb = p.total < 512 ? p.total : 512;
+  hipLaunchKernelGGL(stem_dgrad_kernel, dim3(nb), dim3(256), 0, s, p);
+  MT_LAUNCH_CHECK();
+  __atomic_fetch_add(&g_stem_launches, 1, __ATOMIC_RELAXED);
   return 0;
 }

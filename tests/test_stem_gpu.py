@@ -144,3 +144,40 @@ def test_stem_direct_weight_gradient(case, hip_device):
     scale = ref.abs().max().item()
     for got, what in ((grads[0], "direct"), (grads[1], "gather form")):
         assert (got - ref).abs().max().item() <= 2e-4 * scale + 1e-3, (what, (got - ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_stem_direct_data_gradient(case, hip_device):
+    """dx of the 7x7 stem: direct kernel (+ reflect fold) vs the gather form vs the fp32 reference"""
+    from masterthesis_amd import hip_ops as ops, _lib
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = _lib.load()
+    name, N, Ci, H, W, pad_mode = case
+    g = torch.Generator().manual_seed(11 + len(name))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, Ci, 7, 7, generator=g) * (Ci * 49) ** -0.5).bfloat16().float()
+    gy = torch.randn(N, 64, H, W, generator=g).bfloat16().float()
+    xr = x.clone().requires_grad_()
+    xp = F.pad(xr, (3,) * 4, mode="reflect") if pad_mode == "reflect" else F.pad(xr, (3,) * 4)
+    F.conv2d(xp, w).backward(gy)
+    grads = []
+    prev = lib.mt_kernel_variant_enable(1, 1)
+    try:
+        for on in (1, 0):
+            lib.mt_kernel_variant_enable(1, on)
+            xd = x.to(hip_device).requires_grad_()
+            y = ops.conv2d(xd, w.to(hip_device), None, stride=1, pad=3, pad_mode=pad_mode)
+            n0 = lib.mt_kernel_variant_launches(1)
+            y.backward(gy.to(hip_device))
+            if on:
+                assert lib.mt_kernel_variant_launches(1) == n0 + 1, "the data gradient was meant to run on the direct kernel"
+            grads.append(xd.grad.float().cpu())
+    finally:
+        lib.mt_kernel_variant_enable(1, prev)
+    ref = xr.grad
+    for got, what in ((grads[0], "direct"), (grads[1], "gather form")):
+        rel = (got - ref).norm().item() / ref.norm().item()
+        assert rel < 5e-3, f"{what}: rel L2 err {rel:.3e}"
+        assert (got - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-2, what
+    d = (grads[0] - grads[1]).abs()
+    assert d.max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3

@@ -45,3 +45,20 @@ for N in (16, 32):
         r.append(t(both) - t(fwd))
     lib.mt_kernel_variant_enable(1, 1)
     print(f"N{N} weight gradient (backward minus forward, x without gradient): gather form {r[0]:.1f} us, direct {r[1]:.1f} us")
+
+for N in (16,):
+    x = ops.canon(torch.randn(N, 3, 256, 256, device=dev)).detach().requires_grad_()
+    w = torch.randn(64, 3, 7, 7, device=dev) * 0.08
+    r = []
+    y0 = ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect")
+    gy = ops.canon(torch.randn_like(y0.float())).detach()
+    for on in (0, 1):
+        lib.mt_kernel_variant_enable(1, on)
+        def fwd():
+            with torch.no_grad(): ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect")
+        def both():
+            x.grad = None
+            ops.conv2d(x, w, None, stride=1, pad=3, pad_mode="reflect").backward(gy)
+        r.append(t(both) - t(fwd))
+    lib.mt_kernel_variant_enable(1, 1)
+    print(f"N{N} data gradient (backward minus forward, weight without gradient): gather form {r[0]:.1f} us, direct {r[1]:.1f} us")
