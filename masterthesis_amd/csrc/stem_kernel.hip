@@ -504,7 +504,6 @@ int mt_launch_stem_wgrad_reduce(const mt_conv_desc* d, const void* ws, int nslab
 // 3 of 16 MFMA rows carry data -- the kernel is bound by the LDS reads of the patch, not by the matrix pipe.
 constexpr int SD_TH = 8, SD_TW = 16;
 constexpr int SD_PH = SD_TH + 6, SD_PW = SD_TW + 6;     // 14 x 22 pixels of dy
-constexpr int SD_WROW = 49 * 64 * 2;                    // bytes of one weight row [tap][co]
 
 struct StemDgradParams {
   const char* dy;       // NHWC [N][H][W][64] bf16
@@ -515,15 +514,17 @@ struct StemDgradParams {
   unsigned dy_bytes, out_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const StemDgradParams p) {
+// The 64 couts are walked in two halves of 32 (one MFMA k-step per tap and half): patch half 19.3 KiB + weight half
+// 12.3 KiB per workgroup -> four workgroups (16 waves) per CU.  The loop is a chain of LDS read -> MFMA pairs, so what
+// it needs is waves to hide the LDS latency behind (with the whole 64 couts resident, two workgroups per CU: 175 us).
+__global__ __launch_bounds__(256, 4) void stem_dgrad_kernel(const StemDgradParams p) {
   constexpr unsigned OOB = 0x80000000u;
-  __shared__ u32x4 smem[(4 * SD_WROW + SD_PH * SD_PW * 128) / 16];
-  char* const sW = reinterpret_cast<char*>(smem);              // [4 ch][49][64] bf16
-  char* const sP = sW + 4 * SD_WROW;                           // [14][22 px][8 chunks of 16 B, chunk ^ (px & 7)]
+  constexpr int WH = 4 * 49 * 64;                              // bytes of a weight half [4 ch][49][32 co]
+  __shared__ u32x4 smem[(WH + SD_PH * SD_PW * 64) / 16];
+  char* const sW = reinterpret_cast<char*>(smem);              // [4 ch][49][32 co] bf16 of the current half
+  char* const sP = sW + WH;                                    // [14][22 px][4 chunks of 16 B, chunk ^ ((px >> 2) & 3)]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  for (int i = tid; i < 4 * SD_WROW / 16; i += 256)
-    reinterpret_cast<u32x4*>(sW)[i] = reinterpret_cast<const u32x4*>(p.wpack)[i];     // rows 0..3 of the pack are contiguous
   const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
 
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const StemDgradParam
   const int lo = xcd * tq + (xcd < tr ? xcd : tr);
   const int cnt = tq + (xcd < tr ? 1 : 0);
   const bool arow = fr < 4;                                   // lanes that hold a real weight row
-  const char* wbase = sW + (arow ? fr : 0) * SD_WROW + fg * 16;
+  const char* wbase = sW + (arow ? fr : 0) * (49 * 64) + fg * 16;
 
   for (int it = slot; it < cnt; it += nslot) {
     const int tile = lo + it;
@@ -541,34 +542,50 @@ __global__ __launch_bounds__(256, 2) void stem_dgrad_kernel(const StemDgradParam
     const int t2 = tile / p.tiles_x;
     const int n = t2 / p.tiles_y;
     const int py0 = (t2 - n * p.tiles_y) * SD_TH, px0 = tx * SD_TW;
-    __syncthreads();                                          // everyone is done with the previous patch (and sW is written)
-    // patch: 14 x 22 pixels x 8 chunks; dy row = py0 + off - 6 + pr, column = px0 + off - 6 + pc (zeros outside dy)
-    for (int i = tid; i < SD_PH * SD_PW * 8; i += 256) {
-      const int ck = i & 7, pix = i >> 3;
-      const int pr = pix / SD_PW, pc = pix - pr * SD_PW;
-      const int y = py0 + p.off - 6 + pr, x = px0 + p.off - 6 + pc;
-      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const unsigned o = ok ? (unsigned)((n * p.H + y) * p.W + x) * 128u + (unsigned)ck * 16u : OOB;
-      const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, o, 0, 0));
-      *reinterpret_cast<u32x4*>(sP + (pix * 8 + (ck ^ (pc & 7))) * 16) = v;
-    }
-    __syncthreads();
     // this wave: tile rows 2 wv, 2 wv + 1; pixel fragment = the 16 columns of a row
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-    for (int dh = 0; dh < 7; dh++) {
+    for (int half = 0; half < 2; half++) {
+      __syncthreads();                                        // everyone is done with the previous patch / weights
+      // weights of this half: [ch][tap][32 co] <- pack [ch][tap][64 co] (16-byte chunks 4 half .. 4 half + 3 of a tap)
+      for (int i = tid; i < WH / 16; i += 256) {
+        const int ck = i & 3, rt = i >> 2;                    // rt = ch * 49 + tap
+        reinterpret_cast<u32x4*>(sW)[i] = *reinterpret_cast<const u32x4*>(p.wpack + ((size_t)rt * 8 + half * 4 + ck) * 16);
+      }
+      // patch half: 14 x 22 pixels x 4 chunks; dy row = py0 + off - 6 + pr, column = px0 + off - 6 + pc (zeros outside
+      // dy).  All loads of a thread are issued before the first LDS store; chunk slot = chunk ^ ((pc >> 2) & 3): the 16
+      // consecutive pixels of a fragment read (pitch 64 B) hit 16 different 16-byte bank groups.
+      constexpr int NLD = (SD_PH * SD_PW * 4 + 255) / 256;    // 5
+      u32x4 pv[NLD];
 #pragma unroll
-      for (int dw = 0; dw < 7; dw++) {
-        const int pc = fr + 6 - dw;
-        const char* w = wbase + (dh * 7 + dw) * 128;
+      for (int j = 0; j < NLD; j++) {
+        const int i = tid + 256 * j;
+        const int ck = i & 3, pix = i >> 2;
+        const int pr = pix / SD_PW, pc = pix - pr * SD_PW;
+        const int y = py0 + p.off - 6 + pr, x = px0 + p.off - 6 + pc;
+        const bool ok = i < SD_PH * SD_PW * 4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned o = ok ? (unsigned)((n * p.H + y) * p.W + x) * 128u + (unsigned)(half * 4 + ck) * 16u : OOB;
+        pv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, o, 0, 0));
+      }
 #pragma unroll
-        for (int kc = 0; kc < 2; kc++) {
-          u32x4 wf = *reinterpret_cast<const u32x4*>(w + kc * 64);
-          if (!arow) wf = u32x4{0u, 0u, 0u, 0u};
+      for (int j = 0; j < NLD; j++) {
+        const int i = tid + 256 * j;
+        const int ck = i & 3, pix = i >> 2;
+        const int pc = pix % SD_PW;
+        if (i < SD_PH * SD_PW * 4) *reinterpret_cast<u32x4*>(sP + (pix * 4 + (ck ^ ((pc >> 2) & 3))) * 16) = pv[j];
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int dh = 0; dh < 7; dh++) {
+#pragma unroll
+        for (int dw = 0; dw < 7; dw++) {
+          const int pc = fr + 6 - dw;
+          u32x4 wf = *reinterpret_cast<const u32x4*>(wbase + (dh * 7 + dw) * 64);
+          if (!arow) wf = u32x4{0u, 0u, 0u, 0u};      // (skipping the read on those lanes with a branch was slower: 170 vs 151 us)
 #pragma unroll
           for (int b = 0; b < 2; b++) {
             const int pr = 2 * wv + b + 6 - dh;
-            const u32x4 xf = *reinterpret_cast<const u32x4*>(sP + ((pr * SD_PW + pc) * 8 + ((kc * 4 + fg) ^ (pc & 7))) * 16);
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(sP + ((pr * SD_PW + pc) * 4 + (fg ^ ((pc >> 2) & 3))) * 16);
             mma_chunk<true>(acc[b], wf, xf);
           }
         }
@@ -606,7 +623,7 @@ int mt_launch_stem_dgrad(const mt_conv_desc* d, const void* dy, const void* pack
   p.total = d->N * p.tiles_x * p.tiles_y;
   p.dy_bytes = (unsigned)((size_t)d->N * d->H * d->W * 128); p.out_bytes = (unsigned)((size_t)d->N * p.Hg * p.Wg * 16);
   if (p.total <= 0) return 0;
-  const int nb = p.total < 512 ? p.total : 512;
+  const int nb = p.total < 1024 ? p.total : 1024;
   hipLaunchKernelGGL(stem_dgrad_kernel, dim3(nb), dim3(256), 0, s, p);
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_stem_launches, 1, __ATOMIC_RELAXED);
