@@ -28,8 +28,8 @@ __device__ __forceinline__ void load_w(const void* wpack, float* sw, int n) {
 // y[px][co] = act(sum_ci x[px][ci] w[co][ci] + b[co])
 template <bool BF16, int COP, int LP>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const u32x4* __restrict__ x, const void* __restrict__ wpack,
-                                                     const float* __restrict__ bias, int nbias, void* __restrict__ y,
-                                                     long npix, int act, float slope) {
+                                                     const float* __restrict__ bias, int nbias, int nco,
+                                                     void* __restrict__ y, long npix, int act, float slope) {
   constexpr int V = Elem<BF16>::V;
   constexpr int Cip = LP * V;
   __shared__ float sw[COP * Cip];
@@ -47,19 +47,26 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const u32x4* __restrict__ x
 #pragma unroll
       for (int e = 0; e < V; e++) xf[e] = 0.f;
     }
+    // only the real output rows are computed (to-RGB: 3 of the 8 padded ones; nco is uniform): the dot products,
+    // DPP sums and above all the activation (tanh on one lane in LP) were what bounded this kernel, not HBM
     float out[COP];
 #pragma unroll
     for (int co = 0; co < COP; co++) {
-      float a = 0.f;
+      out[co] = 0.f;
+      if (co < nco) {
+        float a = 0.f;
 #pragma unroll
-      for (int e = 0; e < V; e++) a += xf[e] * sw[co * Cip + chunk * V + e];
-      out[co] = lp_sum<LP>(a);
+        for (int e = 0; e < V; e++) a += xf[e] * sw[co * Cip + chunk * V + e];
+        out[co] = lp_sum<LP>(a);
+      }
     }
     if (ok && chunk == 0) {
 #pragma unroll
       for (int co = 0; co < COP; co++) {
-        const float b = (bias != nullptr && co < nbias) ? bias[co] : 0.f;
-        out[co] = act_apply(out[co] + b, act, slope);
+        if (co < nco) {
+          const float b = (bias != nullptr && co < nbias) ? bias[co] : 0.f;
+          out[co] = act_apply(out[co] + b, act, slope);
+        }
       }
       u32x4* yp = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y) + px * COP * Elem<BF16>::SZ);
 #pragma unroll
@@ -181,7 +188,7 @@ int mt_pw_fwd(const mt_conv_desc* d, const void* x, const void* wpack, const flo
               hipStream_t s) {
   const long groups = npix * (mt_padc(d->Ci) / (d->dtype == MT_BF16 ? 8 : 4));
   const int grid = (int)min((long)8192, (groups + 255) / 256);
-  PW_DISPATCH(pw_fwd_kernel, (const u32x4*)x, wpack, bias, d->Co, y, npix, d->act, d->slope);
+  PW_DISPATCH(pw_fwd_kernel, (const u32x4*)x, wpack, bias, bias ? d->Co : 0, d->Co, y, npix, d->act, d->slope);
   MT_LAUNCH_CHECK();
   return 0;
 }
