@@ -219,9 +219,13 @@ static int scatter_splitk(const mt_conv_desc* d, int Hd, int Wd, int Cin_p, int 
 }
 
 // split_ws: optional fp32 workspace of scatter_splitk(...) * N*Hd*Wd*Cout_p floats for the split-K partial slabs
+// interior / iP: optional second destination for the pixels [iP, Hd-iP) x [iP, Wd-iP) of the (Hd, Wd) grid (the
+// un-padded gradient map of a reflection-padded convolution): used -- return value 100 -- only when the persistent
+// gather-GEMM takes the launch; then `out` receives the border ring only and the caller folds just that.
 static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win, int Cin_p, const void* pack,
                         const float* bias, int nbias, void* out, int Hd, int Wd, int Cout_p, int e, int act,
-                        hipStream_t s, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
+                        hipStream_t s, void* split_ws = nullptr, size_t split_ws_bytes = 0, void* interior = nullptr,
+                        int iP = 0) {
   const int sz = esz(d->dtype), V = vec(d->dtype), st = d->stride;
   MT_CHECK(st * st <= MT_MAX_PHASES, "conv: stride %d has too many phases", st);
   IgemmParams p;
@@ -281,6 +285,10 @@ static int scatter_form(const mt_conv_desc* d, const void* in, int Hin, int Win,
     if (mt_launch_igemm(d->dtype, p, s)) return 2;
     return mt_launch_splitk_finish(d->dtype, (const float*)split_ws, ks, (long)d->N * Hd * Wd * Cout_p, bias, nbias,
                                    Cout_p, out, act, d->slope, s);
+  }
+  if (interior != nullptr && iP > 0 && Hd > 2 * iP && Wd > 2 * iP && mt_igemm_would_persist(d->dtype, p)) {
+    p.y2 = (char*)interior; p.y2P = iP; p.y2H = Hd - 2 * iP; p.y2W = Wd - 2 * iP;
+    return mt_launch_igemm(d->dtype, p, s) ? 2 : 100;
   }
   return mt_launch_igemm(d->dtype, p, s);
 }
@@ -497,9 +505,12 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
     // (3) fold the ring onto the border band
     return mt_launch_ring_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
   }
-  if (scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s,
-                   split_ws, split_b))
-    return 2;
+  // the padded gradient map: whole into the workspace + full fold, or -- on the persistent gather-GEMM -- its interior
+  // straight into dx, only the P-wide ring into the workspace, and the band-only fold (saves a read and a write of dx)
+  const int rc = scatter_form(d, dy, Ho, Wo, Cop, pack_bwd, nullptr, 0, ws, d->H + 2 * P, d->W + 2 * P, Cip, 0, MT_ACT_NONE, s,
+                              split_ws, split_b, dx, P);
+  if (rc == 100) return mt_launch_ring_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
+  if (rc) return 2;
   return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
 }
 

@@ -426,10 +426,11 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 
 template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s);   // conv_pipe_kernel.hip
-int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s);          // conv_persist_kernel.hip
+int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool dry);          // conv_persist_kernel.hip
 
+// dry: launch nothing; return 100 if the persistent kernel would take the problem, 101 otherwise
 template <bool BF16>
-static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
+static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
   // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
   // MT_IGEMM_FORCE (diagnostics, tools/layer_table.py): 1 = 2-stage kernel only, 2 = 4-wave ring variant wherever legal,
   // 3 = 128x512 tiles wherever legal, 4 = 256x256 tiles wherever legal, 5 = 64-channel tiles for Cout % 128 == 0
@@ -474,23 +475,24 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s) {
     for (int i = 1; i < p.nphase; i++) eq = eq && p.ph[i].nblk == p.ph[0].nblk;
     p.interleave = eq ? 1 : 0;
   }
-  if (total == 0) return 0;
+  if (total == 0) return dry ? 101 : 0;
   // 256x256 and 128x512 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
-  if (PT >= 256) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+  if (PT >= 256) return dry ? 101 : launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   // launches that do not fill the chip (latency-bound k loops): the 4-wave ring variant
   {
     bool ok = (WT == 128 || WT == 64) && !p.raw && p.cpc % 4 == 0 && p.x_bytes < 0x7f000000u &&
               (total <= 256 || force == 2) && force != 1;
     for (int i = 0; i < p.nphase && ok; i++) ok = p.ph[i].ntaps <= 9 && p.ph[i].w_bytes < 0x7f000000u;
-    if (ok) return launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
+    if (ok) return dry ? 101 : launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   }
   // several tiles per workgroup slot: the persistent kernel pipelines across tiles (conv_persist_kernel.hip)
   if constexpr (BF16) {
     if (force != 1) {
-      const int r = launch_igemm_persist(p, WT, total, s);
+      const int r = launch_igemm_persist(p, WT, total, s, dry);
       if (r >= 0) return r;
     }
   }
+  if (dry) return 101;
   if (WT == 128) hipLaunchKernelGGL((igemm_kernel<BF16, 128, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 64) hipLaunchKernelGGL((igemm_kernel<BF16, 64, 128, 256>), dim3(total), dim3(256), 0, s, p);
   else if (WT == 32) hipLaunchKernelGGL((igemm_kernel<BF16, 32, 128, 256>), dim3(total), dim3(256), 0, s, p);
@@ -623,7 +625,16 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
     MT_LAUNCH_CHECK();
     return 0;
   }
+  MT_CHECK(q.y2 == nullptr || mt_igemm_would_persist(dtype, p), "igemm: a second destination needs the persistent kernel");
   return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
+}
+bool mt_igemm_would_persist(int dtype, const IgemmParams& p) {
+  if (dtype != MT_BF16 || p.nphase < 1 || p.cpc < 1) return false;
+  IgemmParams q = p;
+  q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
+  q.korder = 1;
+  if (thin_dot_ok(q)) return false;
+  return launch_igemm_t<true>(q, nullptr, true) == 100;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -50,6 +50,9 @@ struct IgemmParams {
   int interleave;     // multi-phase launches whose phases have equal block counts: block b -> (phase b % nphase, tile b / nphase),
                       // so the sub-pixel phases of one input region run side by side and share it in L2
   int korder;         // ping-pong kernel: 1 = walk K channel-slice-major (all taps of a 32-channel slice, then the next slice)
+  char* y2;           // optional second destination (persistent gather-GEMM only, mt_igemm_would_persist): output pixels
+  int y2P, y2H, y2W;  // inside [y2P, y2P+y2H) x [y2P, y2P+y2W) of the (Hout, Wout) grid go to y2 -- an [N][y2H][y2W][Co] tensor,
+                      // at (oh - y2P, ow - y2P) -- instead of y: the interior of a padded gradient map straight into dx
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements
                       // whatever the storage type); mt_launch_splitk_finish sums the slabs
   short dh[MT_MAX_TAPS];
@@ -85,6 +88,8 @@ struct PackParams {
 };
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
+// would mt_launch_igemm run this problem on the persistent kernel (the only one that honours IgemmParams::y2)?
+bool mt_igemm_would_persist(int dtype, const IgemmParams& p);
 // y[i] = act(sum_s slabs[s][i] + bias[i % Cp])  (i over `total` NHWC elements, fp32 slabs, output in `dtype`)
 int mt_launch_splitk_finish(int dtype, const float* slabs, int nsplit, long total, const float* bias, int nbias,
                             int Cp, void* y, int act, float slope, hipStream_t s);

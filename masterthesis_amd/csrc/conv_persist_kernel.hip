@@ -34,7 +34,14 @@ __device__ __forceinline__ void pk_wait_young(int young) {
     case 7: pk_wait_vm<7>(); break;
     case 8: pk_wait_vm<8>(); break;
     case 9: pk_wait_vm<9>(); break;
-    default: pk_wait_vm<0>(); break;       // (never more than 9: waiting for everything is always correct)
+    case 10: pk_wait_vm<10>(); break;
+    case 11: pk_wait_vm<11>(); break;
+    case 12: pk_wait_vm<12>(); break;
+    case 13: pk_wait_vm<13>(); break;
+    case 14: pk_wait_vm<14>(); break;
+    case 15: pk_wait_vm<15>(); break;
+    case 16: pk_wait_vm<16>(); break;
+    default: pk_wait_vm<0>(); break;       // (never more than 16: waiting for everything is always correct)
   }
 }
 // exact floor(m / d) for 0 <= m < 2^24, 0 < d < 2^24 with inv = 1.0f / d (one correction step each way)
@@ -56,7 +63,9 @@ __device__ __forceinline__ void pk_barrier() {
 constexpr int persist_max_co(int WT) { return WT == 128 ? 2048 : 128; }
 
 // AUX: cache policy bits of the output stores (0 = default, 2 = nt: streaming)
-template <int WT, int BPC, int AUX>
+// DUAL: IgemmParams::y2 is set -- every output chunk is stored twice, once per destination, with the lanes that
+// belong to the other one out of range (a buffer store is dropped there): the store count stays a constant
+template <int WT, int BPC, int AUX, bool DUAL>
 __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmParams p, const int total, const int grp,
                                                                  const unsigned w_total, const unsigned y_total) {
   constexpr int PT = 128;
@@ -71,17 +80,19 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   constexpr unsigned OOB = 0x80000000u;
   constexpr int MT_PERSIST_MAX_CO = persist_max_co(WT);
   static_assert(WT == 128 || WT == 64, "tile geometries of the persistent kernel");
-  static_assert(NST % SPK == 0 && NST + 1 <= 9, "store groups / counted-wait range");
+  constexpr int SMUL = DUAL ? 2 : 1;          // store instructions per held chunk
+  static_assert(NST % SPK == 0 && NST * SMUL <= 16, "store groups / counted-wait range");
 
   // ONE shared array (separate __shared__ objects next to an LDS-DMA target make hipcc drain vmcnt):
   // 2 stages of weight tile, 2 stages of pixel tile, the filter-tap table of the launch, the bias vector
-  __shared__ u32x4 smem[2 * SW + 2 * SX + MT_MAX_TAPS / 4 + MT_PERSIST_MAX_CO / 4 + PT + PT / 2];
+  __shared__ u32x4 smem[2 * SW + 2 * SX + MT_MAX_TAPS / 4 + MT_PERSIST_MAX_CO / 4 + PT + PT / 2 + (DUAL ? PT / 2 : 0)];
   u32x4* const sWb = smem;
   u32x4* const sXb = smem + 2 * SW;
   int* const sTap = reinterpret_cast<int*>(smem + 2 * SW + 2 * SX);                           // [MT_MAX_TAPS]
   float* const sBias = reinterpret_cast<float*>(smem + 2 * SW + 2 * SX + MT_MAX_TAPS / 4);   // [MT_PERSIST_MAX_CO]
   u32x2* const sRow = reinterpret_cast<u32x2*>(smem + 2 * SW + 2 * SX + MT_MAX_TAPS / 4 + MT_PERSIST_MAX_CO / 4);   // [2][PT]
   unsigned* const sOut = reinterpret_cast<unsigned*>(sRow + 2 * PT);                           // [2][PT]
+  unsigned* const sOut2 = sOut + 2 * PT;                                                       // [2][PT] (DUAL: offsets into y2)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -131,6 +142,8 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_total, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, y_total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(DUAL ? p.y2 : p.y), 0, DUAL ? (unsigned)p.N * (unsigned)(p.y2H * p.y2W) * (unsigned)(p.Co * 2) : 0u, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   // launch-wide tables
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
       const float inv_hw = 1.0f / (float)HoWo, inv_w = 1.0f / (float)ph_Wo;
       const int m = pt * PT + tid;
       u32x2 rowv = {0u, 0xffffffffu};
-      unsigned yo = OOB;
+      unsigned yo = OOB, yo2 = OOB;
       if (m < ph.M) {
         const int n = pk_div(m, HoWo, inv_hw);
         const int rem = m - n * HoWo;
@@ -174,9 +187,17 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
         const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
         if ((unsigned)oh < (unsigned)p.Hout && (unsigned)ow < (unsigned)p.Wout)
           yo = ph.y_off + (unsigned)((n * p.Hout + oh) * p.Wout + ow) * (unsigned)(p.Co * 2);
+        if constexpr (DUAL) {
+          const int ih = oh - p.y2P, iw = ow - p.y2P;
+          if (yo != OOB && (unsigned)ih < (unsigned)p.y2H && (unsigned)iw < (unsigned)p.y2W) {
+            yo2 = (unsigned)((n * p.y2H + ih) * p.y2W + iw) * (unsigned)(p.Co * 2);
+            yo = OOB;
+          }
+        }
       }
       sRow[par * PT + tid] = rowv;
       sOut[par * PT + tid] = yo;
+      if constexpr (DUAL) sOut2[par * PT + tid] = yo2;
     }
     tap = pk_div(c, p.cpc, inv_cpc);
     cq = c - tap * p.cpc;
@@ -242,12 +263,16 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
 
   // ---- outputs of the finished tile, held in registers until the next tile's k-steps store them ----
   u32x4 held[FC / 2][FP];
-  unsigned hoff[FP], hco[FC / 2];
+  unsigned hoff[FP], hoff2[FP], hco[FC / 2];
   int held_grp = NST / SPK;          // next group of SPK stores to issue (NST / SPK = nothing held)
   auto store_one = [&](int s) {      // s is a compile-time constant after unrolling
     const int sp = s / FP, b = s % FP;
     const unsigned o = ((hoff[b] | hco[sp]) & OOB) ? OOB : hoff[b] + hco[sp];
     __builtin_amdgcn_raw_buffer_store_b128(held[sp][b], rsy, o, 0, AUX);
+    if constexpr (DUAL) {
+      const unsigned o2 = ((hoff2[b] | hco[sp]) & OOB) ? OOB : hoff2[b] + hco[sp];
+      __builtin_amdgcn_raw_buffer_store_b128(held[sp][b], rsy2, o2, 0, AUX);
+    }
   };
   auto store_group = [&](int g) {
 #pragma unroll
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
           if (held_grp < NST / SPK) {
             store_group(held_grp);
             held_grp++;
-            young += SPK;
+            young += SPK * SMUL;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -352,7 +377,7 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
     while (held_grp < NST / SPK) {
       store_group(held_grp);
       held_grp++;
-      young += SPK;
+      young += SPK * SMUL;
     }
     // bias + activation, pack to bf16, keep
 #pragma unroll
@@ -381,7 +406,10 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
       }
     }
 #pragma unroll
-    for (int b = 0; b < FP; b++) hoff[b] = sOut[c_par * PT + wpI * WP + b * 16 + fr];
+    for (int b = 0; b < FP; b++) {
+      hoff[b] = sOut[c_par * PT + wpI * WP + b * 16 + fr];
+      if constexpr (DUAL) hoff2[b] = sOut2[c_par * PT + wpI * WP + b * 16 + fr];
+    }
     held_grp = 0;
     if (!has_next) break;
     it = it_next;
@@ -419,7 +447,7 @@ extern "C" int mt_kernel_variant_enable(int which, int enable) {
 }
 
 // -> 0 launched, 1 error, -1 not applicable (the caller falls back to the per-tile kernels)
-int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s) {
+int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool dry) {
   if (!persist_enabled()) return -1;
   if (p.raw || p.stats != nullptr || (WT != 128 && WT != 64) || p.act == MT_ACT_TANH) return -1;
   const int cus = 256;
@@ -439,16 +467,24 @@ int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s) {
       p.Co > persist_max_co(WT) - 8)
     return -1;
   static const int aux = getenv("MT_PK_STORE_AUX") ? atoi(getenv("MT_PK_STORE_AUX")) : 2;
+  if (p.y2 != nullptr && (unsigned long long)p.N * p.y2H * p.y2W * p.Co * 2ull >= 0x7f000000ull) return -1;
+  if (dry) return 100;
   // tiles of one pixel tile that are consecutive in the launch's tile order: its weight tiles, times its phases
   int grp = ((p.CoRows + WT - 1) / WT) * (p.interleave ? p.nphase : 1);
   grp = grp < 1 ? 1 : (grp > 16 ? 16 : grp);
   // ... but never so large that blocks stay without work: at least two groups per block
   while (grp > 1 && total / grp < 2 * nb) grp = (grp + 1) / 2;
   const unsigned wb = (unsigned)w_total, yb = (unsigned)y_total;
-  if (WT == 128 && aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 2>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
-  else if (WT == 128) hipLaunchKernelGGL((igemm_persist_kernel<128, 2, 0>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
-  else if (aux == 2) hipLaunchKernelGGL((igemm_persist_kernel<64, 3, 2>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
-  else hipLaunchKernelGGL((igemm_persist_kernel<64, 3, 0>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb);
+  const bool dual = p.y2 != nullptr;
+#define PK_LAUNCH(W, B, A, D) hipLaunchKernelGGL((igemm_persist_kernel<W, B, A, D>), dim3(nb), dim3(256), 0, s, p, total, grp, wb, yb)
+  if (WT == 128) {
+    if (dual) { if (aux == 2) PK_LAUNCH(128, 2, 2, true); else PK_LAUNCH(128, 2, 0, true); }
+    else { if (aux == 2) PK_LAUNCH(128, 2, 2, false); else PK_LAUNCH(128, 2, 0, false); }
+  } else {
+    if (dual) { if (aux == 2) PK_LAUNCH(64, 3, 2, true); else PK_LAUNCH(64, 3, 0, true); }
+    else { if (aux == 2) PK_LAUNCH(64, 3, 2, false); else PK_LAUNCH(64, 3, 0, false); }
+  }
+#undef PK_LAUNCH
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_persist_launches, 1, __ATOMIC_RELAXED);
   return 0;
