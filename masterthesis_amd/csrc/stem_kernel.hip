@@ -241,7 +241,8 @@ int mt_launch_stem_fwd(const mt_conv_desc* d, const void* x, const void* pack, c
   p.total = d->N * p.tiles_x * p.tiles_y;
   p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
   if (p.total <= 0) return 0;
-  const int nb = p.total < 768 ? p.total : 768;
+  static const int cap = getenv("MT_STEM_FWD_BLOCKS") ? atoi(getenv("MT_STEM_FWD_BLOCKS")) : 768;
+  const int nb = p.total < cap ? p.total : cap;
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(nb), dim3(256), 0, s, p);
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_stem_launches, 1, __ATOMIC_RELAXED);
