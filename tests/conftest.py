@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Under `pytest -x` one red test hides everything collected after it (round 2: a self-comparison in test_persist_gpu
+# stopped the driver's run before the 62 reference-fixture tests).  Parity against the reference's recorded fixtures
+# runs FIRST, then the kernels against the fp32 reference of each op, then properties and self-comparisons.
+_ORDER = ["test_step_gpu", "test_stem_gpu", "test_ops_gpu", "test_ops_round2_gpu", "test_ops_round3_gpu", "test_direct_gpu",
+          "test_oracle_golden", "test_host_cpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+    items.sort(key=rank)            # stable: the order inside a module and among the rest stays as collected
+
+
 @pytest.fixture(scope="session")
 def hip_device():
     import torch

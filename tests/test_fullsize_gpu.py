@@ -6,6 +6,8 @@ identities and the batched calls through batch-split invariance:
 
 which exercises, at the sizes the bench runs, the 256x256 / 128x512 ping-pong kernels, the interior+ring data
 gradient, the 256x256 weight-gradient kernel + unpack, split-K and the streaming class-head kernel."""
+import zlib
+
 import pytest
 import torch
 
@@ -39,7 +41,7 @@ def test_conv_adjoint_identities(shape, dtype, hip_device):
     from masterthesis_amd import hip_ops as ops
     ops.set_compute_dtype(dtype)
     name, tr, N, Ci, H, W, Co, k, stride, pad, pad_mode, out_pad = shape
-    g = torch.Generator(device="cpu").manual_seed(hash(name) % (1 << 31))
+    g = torch.Generator(device="cpu").manual_seed(zlib.crc32(name.encode()))   # fixed per shape (hash() of a string is per process)
 
     def rnd(*s, scale=1.0):
         t = torch.randn(*s, generator=g) * scale

@@ -3,6 +3,8 @@ both accumulate the same MFMA fragments in the same order -- and against the fp3
 Shapes have at least two 128-pixel tiles per resident workgroup (the dispatcher's condition: 1024 tiles for more
 than 64 output channels, 1536 up to 64), ragged pixel counts, partial channel tiles,
 several sub-pixel phases (stride-2 data gradient, transposed convolution) and short reductions (1-2 k-steps)."""
+import zlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -29,9 +31,62 @@ CASES = [
 ]
 
 
+def case_seed(name):
+    """A fixed seed per case (Python's hash() of a string changes from process to process)."""
+    return zlib.crc32(name.encode()) % 1000
+
+
+def reference(case, x, w, b, gy, y_dev=None):
+    """fp32 CPU reference of the op: (y, dx through the reference's own activation mask, dx through the DEVICE's mask).
+
+    The activation derivative is a step function of the pre-activation; two fp32 summation orders of the same
+    convolution disagree on the sign of a few pre-activations that sit within rounding of zero, and one flipped mask
+    entry moves k*k*Ci elements of dx by gy*w (4 of 24 seeds exceed an element-wise bound with no GPU
+    involved).  So the element-wise placement check uses the gradient that follows from the device's own mask
+    (y_dev > 0) -- it isolates the GEMM, the ring and the fold -- and the reference's mask is kept for the rel-L2 check."""
+    name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
+    xr = x.clone().requires_grad_()
+    if kind == "conv":
+        xp = F.pad(xr, (pad,) * 4, mode="reflect") if (pad_mode == "reflect" and pad) else xr
+        pre = F.conv2d(xp, w, b, stride=stride, padding=0 if (pad_mode == "reflect" and pad) else pad)
+    else:
+        pre = F.conv_transpose2d(xr, w, b, stride=stride, padding=pad, output_padding=1)
+    slope = {"relu": 0.0, "lrelu": 0.01}.get(act)
+    yr = pre if slope is None else torch.where(pre > 0, pre, pre * slope)
+    (dx_ref,) = torch.autograd.grad(yr, xr, gy, retain_graph=True)
+    dx_dev_mask = dx_ref
+    if slope is not None and y_dev is not None:
+        d = torch.where(y_dev > 0, torch.ones_like(gy), torch.full_like(gy, slope))
+        (dx_dev_mask,) = torch.autograd.grad(pre, xr, gy * d)
+    return yr.detach(), dx_ref, dx_dev_mask, pre.detach()
+
+
+def check_against_reference(case, x, w, b, gy, y_dev, dx_dev):
+    """rel-L2 of forward and data gradient against the fp32 reference; element-wise bound (no tile missing or
+    misplaced: the worst element error stays at bf16 rounding of the largest value) on the forward and on the data
+    gradient through the device's own activation mask.  On failure the message names the element."""
+    yr, dx_ref, dx_mask, pre = reference(case, x, w, b, gy, y_dev)
+    for got, ref, what in ((y_dev, yr, "fwd"), (dx_dev, dx_ref, "dx")):
+        rel = (got - ref).norm().item() / (ref.norm().item() + 1e-12)
+        assert rel < 1e-2, f"{case[0]} {what}: rel L2 err {rel:.3e}"
+    for got, ref, what in ((y_dev, yr, "fwd"), (dx_dev, dx_mask, "dx (device mask)")):
+        err = (got - ref).abs()
+        bound = 0.03 * ref.abs().max().item() + 0.02
+        worst = err.max().item()
+        if worst > bound:
+            idx = [int(i) for i in torch.unravel_index(err.argmax(), err.shape)]
+            near0 = ""
+            if what == "fwd":
+                near0 = f", pre-activation there {pre[tuple(idx)].item():.3e}"
+            raise AssertionError(f"{case[0]} {what}: |got - ref| = {worst:.4e} > {bound:.4e} at (n, c, h, w) = {idx}: "
+                                 f"got {got[tuple(idx)].item():.6e}, ref {ref[tuple(idx)].item():.6e}{near0}; "
+                                 f"elements over the bound: {int((err > bound).sum())}; "
+                                 f"pre-activations within 1e-5 of 0: {int((pre.abs() < 1e-5).sum())}")
+
+
 def _run(ops, case, dev):
     name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(case_seed(name))
     x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
     wshape = (Co, Ci, k, k) if kind == "conv" else (Ci, Co, k, k)
     w = (torch.randn(*wshape, generator=g) * (Ci * k * k) ** -0.5).bfloat16().float()
@@ -69,20 +124,4 @@ def test_persistent_matches_per_tile_kernel(case, hip_device):
     assert torch.equal(y1, y0), f"forward differs: max {(y1 - y0).abs().max().item():.3e}"
     assert torch.equal(dx1, dx0), f"data gradient differs: max {(dx1 - dx0).abs().max().item():.3e}"
     # ... and both against the op's fp32 reference
-    name, kind, N, Ci, H, W, Co, k, stride, pad, pad_mode, bias, act = case
-    xr = x.clone().requires_grad_()
-    if kind == "conv":
-        xp = F.pad(xr, (pad,) * 4, mode="reflect") if (pad_mode == "reflect" and pad) else xr
-        yr = F.conv2d(xp, w, b, stride=stride, padding=0 if (pad_mode == "reflect" and pad) else pad)
-    else:
-        yr = F.conv_transpose2d(xr, w, b, stride=stride, padding=pad, output_padding=1)
-    if act == "relu":
-        yr = F.relu(yr)
-    elif act == "lrelu":
-        yr = F.leaky_relu(yr, 0.01)
-    yr.backward(gy)
-    for got, ref, what in ((y1, yr.detach(), "fwd"), (dx1, xr.grad, "dx")):
-        rel = (got - ref).norm().item() / (ref.norm().item() + 1e-12)
-        assert rel < 1e-2, f"{what}: rel L2 err {rel:.3e}"
-        # no tile may be missing or misplaced: the worst element error stays at bf16 rounding of the largest value
-        assert (got - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 0.02, what
+    check_against_reference(case, x, w, b, gy, y1, dx1)
