@@ -64,11 +64,13 @@ const char* mt_last_error(void);
 int mt_version(void);
 /* launches routed so far to a kernel variant the dispatcher chooses by problem size (tests assert that a shape class
  * really exercised the variant it is meant to cover): which = 0 persistent gather-GEMM (conv_persist_kernel.hip),
- * 1 direct 7x7 stem forward (stem_kernel.hip; same values up to fp32 summation order) */
+ * 1 direct 7x7 stem forward (stem_kernel.hip; same values up to fp32 summation order),
+ * 2 patch-resident gather-GEMM (conv_patch_kernel.hip: stride-1 gathers with 1 or 4 phases whose pixel tile's input
+ *   patch stays in LDS; same values up to fp32 summation order -- its K loop walks channel slices first) */
 long mt_kernel_variant_launches(int which);
 /* switch such a variant off / on again (tests compare it bit for bit with the kernel it replaces; both are
  * results-identical by construction); returns the previous setting.  MT_IGEMM_PERSIST=0 in the environment disables
- * variant 0 from the start. */
+ * variant 0 from the start, MT_IGEMM_PATCH=0 variant 2. */
 int mt_kernel_variant_enable(int which, int enable);
 static inline int mt_padc(int c) { return (c + 7) & ~7; }
 

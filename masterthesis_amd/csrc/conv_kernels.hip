@@ -427,8 +427,9 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
 template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s);   // conv_pipe_kernel.hip
 int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool dry);          // conv_persist_kernel.hip
+int launch_igemm_patch(IgemmParams& p, hipStream_t s, bool dry);                                // conv_patch_kernel.hip
 
-// dry: launch nothing; return 100 if the persistent kernel would take the problem, 101 otherwise
+// dry: launch nothing; return 100 if a kernel that honours IgemmParams::y2 (persistent / patch-resident) would take the problem, 101 otherwise
 template <bool BF16>
 static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
   // tile geometry: 256x256 tiles when a single-phase problem gives (a multiple of) one block per CU
@@ -443,6 +444,15 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
     const int n256 = cdiv(p.ph[0].M, 256) * (p.CoRows / 256);
     if ((n256 >= 192 && (n256 % 256 == 0 || n256 >= 1024)) || force == 4) { PT = 256; WT = 256; }
     if (force == 1 || force == 2 || force == 3) { PT = 128; WT = 128; }
+  }
+  // stride-1 gathers whose pixel tile's input patch fits LDS: the patch-resident kernel (conv_patch_kernel.hip) stages
+  // every pixel once per channel slice instead of once per tap, and computes the four sub-pixel phases of a scatter
+  // form from one patch
+  if constexpr (BF16) {
+    if (!(PT == 256 && WT == 256) && force == 0) {
+      const int r = launch_igemm_patch(p, s, dry);
+      if (r >= 0) return r;
+    }
   }
   // 128 couts x 512 pixels ping-pong tiles for the Cout = 128 layers (any number of phases, <= 9 taps each)
   if (WT == 128 && PT == 128 && !p.raw && p.stats == nullptr && p.CoRows % 128 == 0 && p.cpc % 4 == 0 &&

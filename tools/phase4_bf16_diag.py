@@ -42,8 +42,9 @@ def run_once(name, precision):
 
         def hooked(closure=None, _net=net, _orig=orig):
             torch.cuda.synchronize()
-            seen.append((_net, torch.cat([p.grad.detach().double().flatten().cpu() for _, p in M.model[_net].named_parameters()
-                                          if p.grad is not None])))
+            named = [(k, p.grad.detach().double().flatten().cpu()) for k, p in M.model[_net].named_parameters()
+                     if p.grad is not None]
+            seen.append((_net, torch.cat([v for _, v in named]), named))
             return _orig()
         opt.step = hooked
     misc.set_random_source(misc.ReplaySource([z[f"rng/0/{i}"] for i in range(meta["rng_counts"][0])]))
@@ -62,6 +63,7 @@ def main():
     ap.add_argument("fixtures", nargs="*", default=FIXTURES)
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--atomics", action="store_true", help="also R bf16 runs with the fused (atomic) statistics epilogue")
+    ap.add_argument("--tensors", action="store_true", help="per-tensor cos / ratio of the phase-4 steps (first bf16 run)")
     o = ap.parse_args()
     from masterthesis_amd import hip_ops as ops
     for name in o.fixtures:
@@ -73,7 +75,7 @@ def main():
                 runs = [run_once(name, "bf16") for _ in range(o.runs)]
             finally:
                 ops.set_deterministic(False)
-            for j, (net, v32) in enumerate(ref):
+            for j, (net, v32, named32) in enumerate(ref):
                 cs, rs, dmax = [], [], 0.0
                 for r in runs:
                     v = r[j][1]
@@ -82,6 +84,11 @@ def main():
                     dmax = max(dmax, (v - runs[0][j][1]).abs().max().item())
                 print(f"PH4DIAG {name:26s} {label:7s} step{j} {net:22s} cos " + " ".join(f"{c:+.3f}" for c in cs) +
                       "  ratio " + " ".join(f"{x:.3f}" for x in rs) + f"  run-to-run max diff {dmax:.2e}", flush=True)
+                if o.tensors and j >= len(ref) - 2:
+                    for (k, a), (_, b) in zip(runs[0][j][2], named32):
+                        c = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
+                        print(f"PH4TENS {name:22s} {label} step{j} {net}.{k:40s} cos {c:+.3f} ratio {(a.norm() / (b.norm() + 1e-300)).item():.3f} "
+                              f"|fp32| {b.norm().item():.3e}", flush=True)
 
 
 if __name__ == "__main__":
