@@ -66,11 +66,14 @@ int mt_version(void);
  * really exercised the variant it is meant to cover): which = 0 persistent gather-GEMM (conv_persist_kernel.hip),
  * 1 direct 7x7 stem forward (stem_kernel.hip; same values up to fp32 summation order),
  * 2 patch-resident gather-GEMM (conv_patch_kernel.hip: stride-1 gathers with 1 or 4 phases whose pixel tile's input
- *   patch stays in LDS; same values up to fp32 summation order -- its K loop walks channel slices first) */
+ *   patch stays in LDS; same values up to fp32 summation order -- its K loop walks channel slices first),
+ * 3 the 256x256 ping-pong gather-GEMM with a patch-resident pixel operand (conv_pipe_patch_kernel.hip; bit-identical to
+ *   the ring kernel it replaces: same fragments, same accumulation order) */
 long mt_kernel_variant_launches(int which);
 /* switch such a variant off / on again (tests compare it bit for bit with the kernel it replaces; both are
  * results-identical by construction); returns the previous setting.  MT_IGEMM_PERSIST=0 in the environment disables
- * variant 0 from the start, MT_IGEMM_PATCH=0 variant 2. */
+ * variant 0 from the start, MT_IGEMM_PATCH=0 variant 2.  Variant 2 has three settings: 0 off, 1 the shapes where it
+ * measured faster inside the training step (default), 2 every shape it can run.  MT_IGEMM_PIPE_PATCH=0 disables variant 3. */
 int mt_kernel_variant_enable(int which, int enable);
 static inline int mt_padc(int c) { return (c + 7) & ~7; }
 

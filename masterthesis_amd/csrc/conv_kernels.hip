@@ -428,6 +428,8 @@ template <bool BF16>
 int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s);   // conv_pipe_kernel.hip
 int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool dry);          // conv_persist_kernel.hip
 int launch_igemm_patch(IgemmParams& p, hipStream_t s, bool dry);                                // conv_patch_kernel.hip
+template <bool BF16>
+int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s);                         // conv_pipe_patch_kernel.hip
 
 // dry: launch nothing; return 100 if a kernel that honours IgemmParams::y2 (persistent / patch-resident) would take the problem, 101 otherwise
 template <bool BF16>
@@ -487,6 +489,11 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
   }
   if (total == 0) return dry ? 101 : 0;
   // 256x256 and 128x512 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
+  if (PT == 256 && WT == 256 && !dry) {
+    // ... with the pixel operand resident in LDS as a patch where the map allows it (conv_pipe_patch_kernel.hip)
+    const int r = launch_igemm_pipe_patch_t<BF16>(p, total, s);
+    if (r >= 0) return r;
+  }
   if (PT >= 256) return dry ? 101 : launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   // launches that do not fill the chip (latency-bound k loops): the 4-wave ring variant
   {

@@ -430,14 +430,16 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(const IgemmParams p
 // ------------------------------------------------------------------------------------------------------------
 static long g_patch_launches = 0;
 static int g_patch_on = -1;
+// 0 = off, 1 = where it measured faster inside the training step (the default), 2 = every shape it can run
+// (tests; tools/bench_patch.py).  MT_IGEMM_PATCH in the environment sets the initial value.
 static int patch_enabled() {
-  if (g_patch_on < 0) g_patch_on = getenv("MT_IGEMM_PATCH") ? (atoi(getenv("MT_IGEMM_PATCH")) != 0) : 1;
+  if (g_patch_on < 0) g_patch_on = getenv("MT_IGEMM_PATCH") ? atoi(getenv("MT_IGEMM_PATCH")) : 1;
   return g_patch_on;
 }
 long mt_patch_launches() { return g_patch_launches; }
 int mt_patch_enable(int on) {
   const int prev = patch_enabled();
-  g_patch_on = on != 0;
+  g_patch_on = on < 0 ? 0 : (on > 2 ? 2 : on);
   return prev;
 }
 
@@ -508,6 +510,13 @@ int launch_igemm_patch(IgemmParams& p, hipStream_t s, bool dry) {
   pl.Ho = Ho; pl.Wo = Wo;
   const long total = (long)p.N * pl.tiles_x * pl.tiles_y * pl.nct;
   if (total >= (1 << 24) || total < 192) return -1;
+  if (patch_enabled() < 2) {
+    // In-step A/B (tools/layer_table.py, profiles/round3_*): the 128-channel single-phase geometry wins where the
+    // reduction is short and the grid large (3x3 64->128 on 128x128: 87 -> 58 us); with 16-MFMA steps (64-channel
+    // tiles) or four phases per step (8-32 MFMAs between barriers) the per-step synchronisation costs more than the
+    // staged bytes save, and small grids leave half the wave slots empty.
+    if (NPH != 1 || !g128 || pl.nsl > 2 || total < 768) return -1;
+  }
   // (tiles overhanging the grid compute masked pixels: refuse shapes that waste more than a third)
   if ((double)pl.tiles_x * TW * pl.tiles_y * TH > 1.5 * (double)Ho * Wo) return -1;
   pl.total = (int)total;

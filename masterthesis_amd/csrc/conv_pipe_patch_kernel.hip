@@ -1,0 +1,346 @@
+// 256 x 256 ping-pong gather-GEMM with a PATCH-RESIDENT pixel operand (same math and parameter block as
+// igemm_pipe_kernel<.., 256, 256, 512, 4, ..> in conv_pipe_kernel.hip, which it replaces for stride-1 gathers on maps whose
+// width is a power of two: the 3x3 256->256 residual-block convolutions, 77 % of the step's FLOPs, forward and the
+// interior of the data gradient).  gfx950 only.
+//
+// Why: in-kernel stamps of the ring kernel put its main loop at 1266 cycles per k-step against 1024 of pure
+// MFMA issue; without any copies it runs 1065, the two weight copies alone cost +12, the two pixel copies alone +50, all
+// four together +200 wherever they are placed -- the LDS-DMA instructions themselves (60-180 issue cycles each beside
+// MFMAs) are the overhead, not their bytes.  The ring kernel already walks K slice-major (all taps of a 32-channel
+// slice back to back) so that the tile's input patch stays in L2 between taps; here that patch -- (TH + span) x (W + span)
+// pixels x 64 bytes, 25 KB for K1 -- is copied into LDS ONCE per slice (double-buffered: slice s+1 lands while slice
+// s computes) and the pixel fragment of a tap is a ds_read_b128 at (pixel + tap offset).  Per k-step a wave then
+// issues 2 weight copies plus at most one patch copy in 4 of 9 steps, instead of 4 copies; the gather-offset table is
+// gone (the patch rows carry reflection / zero padding, resolved once per tile).
+//
+// Everything else is igemm_pipe_kernel: 8 waves = two groups of four in ping-pong (memory phase / 32 MFMAs), 4-stage
+// weight ring with a counted s_waitcnt vmcnt, permuted weight rows for 16-byte epilogue stores, fused per-(image,
+// channel) statistics.  The count of copies per step varies (2 or 3), so the wait picks one of three immediates.
+#include "conv_device.h"
+#include <stdlib.h>
+
+constexpr int MT_PP_PCAP = 544;          // rows of a patch slot (4 x 130 for 128-wide maps, 8 x 68 for 5x5 taps on 64-wide ones)
+constexpr int MT_PP_MAXTAPS = 25;
+
+template <bool BF16>
+__global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams p, const int PH, const int PW, const int dh0,
+                                                               const int dw0, const int wo_shift) {
+  constexpr int WT = 256, PT = 256, NT = 512, NS = 4, NW = 8;
+  constexpr int WC = 128, WP = 64, NWP = PT / WP, FC = WC / 16, FP = WP / 16;
+  constexpr int SZ = BF16 ? 2 : 4;
+  constexpr int NWL = 2;                       // weight copies per wave per stage
+  constexpr int STAGE = WT * 4;                // u32x4 per weight stage (256 rows x 64 B)
+  constexpr int PCAP = MT_PP_PCAP;
+  constexpr int NPW = (PCAP / 16 + NW - 1) / NW;       // patch copies per wave per slice (at most)
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(NPW <= 5, "literal-sized arrays");
+  static_assert((NS * STAGE + 2 * PCAP * 4) * 16 + 32 * 4 <= 160 * 1024, "LDS budget");
+
+  // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt)
+  __shared__ u32x4 smem[NS * STAGE + 2 * PCAP * 4 + 8];
+  u32x4* const sP = smem + NS * STAGE;
+  int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);        // [<= 25 (+ pad)] patch row offset per tap
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int wcI = wv / NWP, wpI = wv % NWP;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const int rsub = lane >> 2, csub = lane & 3;
+
+  const IgemmPhase& ph = p.ph[0];
+  const int ntaps = ph.ntaps, ph_Wo = ph.Wo, ph_M = ph.M;
+  const int HoWo = ph.Ho * ph_Wo;
+  const int nWT = p.CoRows / WT;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wt = wg % nWT, pt = wg / nWT;
+  const int nsl = p.cpc >> 2;                  // 64-byte channel slices
+  const int nk = ntaps * nsl;
+
+  if (tid < 32) sQ[tid] = tid < ntaps ? ((int)p.dh[ph.tap0 + tid] - dh0) * PW + ((int)p.dw[ph.tap0 + tid] - dw0) : 0;
+
+  // ---- the tile: 256 consecutive pixels of one image = TH full rows (host: 256 % Wo == 0, HoWo % 256 == 0) ----
+  const int m0 = pt * PT;
+  const int n0 = m0 / HoWo;
+  const int ho0 = (m0 - n0 * HoWo) >> wo_shift;
+  const int prows = PH * PW;
+  const int npp = (prows + 15) >> 4;                                   // copies per slice
+  const int nmine = npp > wvu ? (npp - wvu + NW - 1) / NW : 0;        // ... of which this wave issues
+  // source offsets of this lane's patch rows (without the slice): reflection / zero padding resolved here
+  unsigned xrow[5];
+  {
+    const unsigned nbase = (unsigned)n0 * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
+    const float inv_pw = 1.0f / (float)PW;
+#pragma unroll
+    for (int j = 0; j < NPW; j++) {
+      const int r = (wvu + NW * j) * 16 + rsub;
+      int py = (int)((float)r * inv_pw);
+      int px = r - py * PW;
+      py = px < 0 ? py - 1 : py; px = px < 0 ? px + PW : px;
+      py = px >= PW ? py + 1 : py; px = px >= PW ? px - PW : px;
+      int hi = ho0 + dh0 + py, wi = dw0 + px;
+      bool ok = r < prows && m0 < ph_M;
+      if (p.pad_mode == MT_PAD_REFLECT) {
+        hi = hi < 0 ? -hi : hi;
+        hi = hi >= p.Hi ? 2 * (p.Hi - 1) - hi : hi;
+        wi = wi < 0 ? -wi : wi;
+        wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
+      }
+      ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+      xrow[j] = ok ? nbase + (unsigned)(hi * p.Wi + wi) * (unsigned)p.Cib + (unsigned)((csub ^ ((r >> 1) & 3)) * 16) : OOB;
+    }
+  }
+  // patch row of this lane's pixel of fragment b at tap offset 0
+  int q0[FP];
+#pragma unroll
+  for (int b = 0; b < FP; b++) {
+    const int tp = wpI * WP + b * 16 + fr;
+    q0[b] = (tp >> wo_shift) * PW + (tp & (ph_Wo - 1));
+  }
+
+  // ---- weight staging (as in igemm_pipe_kernel) ----
+  unsigned wo32[2];
+#pragma unroll
+  for (int i = 0; i < NWL; i++) {
+    const int rs = 16 * (wvu + NW * i) + rsub;           // LDS row of the weight tile (fragment order)
+    // channel held by that row: within each 32-row fragment pair, row (a&1)*16 + r <- channel (r>>2)*8 + (a&1)*4 + (r&3)
+    const int rl = (rs & ~31) | ((((rs & 15) >> 2) << 3) | (((rs >> 4) & 1) << 2) | (rs & 3));
+    const int row = wt * WT + rl;
+    wo32[i] = row < p.CoRows ? ((unsigned)row * (unsigned)ph.wrow + (unsigned)(csub ^ ((rsub >> 1) & 3))) * 16u : OOB;
+  }
+  int tap_s = 0, sl_s = 0;      // wave-uniform: tap and slice of the NEXT weight stage to issue (slice-major K order)
+  unsigned wk = 0;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + ph.w_off), 0, ph.w_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  char* const lds0 = reinterpret_cast<char*>(&smem[0]);
+  char* const ldsP = reinterpret_cast<char*>(sP);
+
+  auto issue_weights = [&](int slot) {
+    // (past the end of K the offsets run past the row / the pack: range-checked zeros or finite weights that meet a
+    //  stage nobody reads)
+    char* base = lds0 + slot * (STAGE * 16);
+#pragma unroll
+    for (int j = 0; j < NWL; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j] + wk, 0, 0, 0);
+    tap_s += 1;
+    const bool wrap = tap_s >= ntaps;
+    sl_s = wrap ? sl_s + 1 : sl_s;
+    tap_s = wrap ? 0 : tap_s;
+    wk = sl_s < nsl ? (unsigned)((tap_s * p.cpc + sl_s * 4) * 16) : 0x40000000u;     // past K: out of range
+  };
+  auto patch_piece = [&](int pslot, int j, int sl) {
+    unsigned off = OOB;
+#pragma unroll
+    for (int jj = 0; jj < NPW; jj++) off = (j == jj) ? xrow[jj] : off;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(ldsP + pslot * (PCAP * 64) + (wvu + NW * j) * 1024), 16,
+                                             off + (unsigned)sl * 64u, 0, 0, 0);
+  };
+
+  f32x4 acc[FC][FP];
+#pragma unroll
+  for (int a = 0; a < FC; a++)
+#pragma unroll
+    for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: patch of slice 0, weight stages 0 .. NS-2 ----
+  for (int j = 0; j < nmine; j++) patch_piece(0, j, 0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; s++) issue_weights(s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NWL) : "memory");
+  __syncthreads();              // sQ visible; every wave's patch rows and stage 0 have landed
+
+  // ---- ping-pong main loop (see igemm_pipe_kernel): waves 0-3 and 4-7 alternate between a MEMORY phase (copies of
+  // stage ks+NS-1 and of the next slice's patch, fragment reads of stage ks) and a COMPUTE phase (32 MFMAs) ----
+  const int grp = wvu >> 2;
+  if (grp) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int slot = 0;                 // ring slot of stage ks
+  int tap_c = 0, sl_c = 0;      // tap / slice being computed
+  int p_j = 0;                  // patch copies of slice sl_c + 1 issued so far
+  int c_prev = NWL;             // copies issued in the previous memory phase
+  for (int ks = 0; ks < nk; ks++) {
+    int fill = slot - 1;
+    fill = fill < 0 ? NS - 1 : fill;
+    u32x4 wf[FC], xf[FP];
+    // copies first: the texture path works on them while the LDS serves the fragment reads.  The next slice's patch
+    // goes out one copy per step in the first steps of this slice (it is read two or more steps after the last one,
+    // behind the counted wait below: ntaps >= nmine + 3, host)
+    int c_now = NWL;
+    if (p_j < nmine && sl_c + 1 < nsl) {
+      patch_piece((sl_c + 1) & 1, p_j, sl_c + 1);
+      p_j++;
+      c_now++;
+    }
+    issue_weights(fill);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const u32x4* sWs = &smem[slot * STAGE];
+      const u32x4* sPs = sP + (sl_c & 1) * (PCAP * 4);
+      const int qo = sQ[tap_c];
+#pragma unroll
+      for (int a = 0; a < FC; a++) {
+        const int row = wcI * WC + a * 16 + fr;
+        wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
+      }
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        const int q = q0[b] + qo;
+        xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
+      }
+    }
+    tap_c++;
+    if (tap_c == ntaps) { tap_c = 0; sl_c++; p_j = 0; }
+    // all but the copies of this and the previous memory phase have landed: stage ks+1 (and, at a slice boundary, the
+    // next slice's patch) is in LDS before the barrier in front of anyone's reads
+    {
+      const int young = c_prev + c_now;      // 2 NWL .. 2 NWL + 2
+      if (young == 2 * NWL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL) : "memory");
+      else if (young == 2 * NWL + 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL + 2) : "memory");
+      c_prev = c_now;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < FC; a++)
+#pragma unroll
+      for (int b = 0; b < FP; b++) mma_chunk<BF16>(acc[a][b], wf[a], xf[b]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot + 1 == NS ? 0 : slot + 1;
+  }
+  if (!grp) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing copies must have landed before LDS is reused / the wave exits
+
+  // ---- epilogue (igemm_pipe_kernel's): bias + activation, packed NHWC store, optional statistics ----
+  char* yp[FP];
+#pragma unroll
+  for (int b = 0; b < FP; b++) {
+    const int m = pt * PT + wpI * WP + b * 16 + fr;
+    yp[b] = nullptr;
+    if (m < ph_M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem >> wo_shift;
+      const int wo = rem & (ph_Wo - 1);
+      const int oh = ho * p.os + ph.oh0, ow = wo * p.os + ph.ow0;
+      if ((unsigned)oh < (unsigned)p.Hout && (unsigned)ow < (unsigned)p.Wout)
+        yp[b] = p.y + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * SZ;
+    }
+  }
+  const bool do_stats = p.stats != nullptr;
+  float* red = reinterpret_cast<float*>(&smem[0]);      // [NWP][WT][2]
+  if (do_stats) __syncthreads();
+#pragma unroll
+  for (int sp = 0; sp < FC / 2; sp++) {
+    const int col = wcI * WC + sp * 32 + fg * 8;
+    const int co = wt * WT + col;
+    if (co >= p.Co) continue;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bv[e] = (p.bias != nullptr && (co + e) < p.nbias) ? p.bias[co + e] : 0.f;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < FP; b++) {
+      if (yp[b] == nullptr) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope);
+        s1[e] += v[e];
+        s2[e] += v[e] * v[e];
+      }
+      if constexpr (BF16) {
+        u32x4 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(yp[b] + (size_t)co * 2));
+      } else {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4) = o0;
+        *reinterpret_cast<f32x4*>(yp[b] + (size_t)co * 4 + 16) = o1;
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+        if (fr == 0) {
+          red[((wpI * WT) + col + e) * 2] = t1;
+          red[((wpI * WT) + col + e) * 2 + 1] = t2;
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    if (m0 < ph_M) {
+      for (int idx = tid; idx < WT * 2; idx += NT) {
+        const int col = idx >> 1;
+        if (wt * WT + col < p.Co) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < NWP; w++) t += red[(w * WT + col) * 2 + (idx & 1)];
+          atomicAdd(p.stats + ((size_t)n0 * p.Co + wt * WT + col) * 2 + (idx & 1), t);
+        }
+      }
+    }
+  }
+}
+
+static long g_pp_launches = 0;
+static int g_pp_on = -1;
+static int pp_enabled() {
+  if (g_pp_on < 0) g_pp_on = getenv("MT_IGEMM_PIPE_PATCH") ? (atoi(getenv("MT_IGEMM_PIPE_PATCH")) != 0) : 1;
+  return g_pp_on;
+}
+long mt_pipe_patch_launches() { return g_pp_launches; }
+int mt_pipe_patch_enable(int on) {
+  const int prev = pp_enabled();
+  g_pp_on = on != 0;
+  return prev;
+}
+
+// -> 0 launched, 1 error, -1 not this kernel's shape (the caller launches igemm_pipe_kernel)
+template <bool BF16>
+int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s) {
+  if (!pp_enabled()) return -1;
+  const IgemmPhase& q = p.ph[0];
+  if (p.nphase != 1 || p.raw || p.is != 1 || p.cpc % 4 != 0 || p.CoRows % 256 != 0) return -1;
+  const int Wo = q.Wo, Ho = q.Ho;
+  if (Wo < 16 || Wo > 256 || (Wo & (Wo - 1)) != 0 || (Ho * Wo) % 256 != 0 || q.M != p.N * Ho * Wo) return -1;
+  if (q.ntaps > MT_PP_MAXTAPS || q.ntaps < 2 || q.y_off != 0) return -1;
+  int shift = 0;
+  while ((1 << shift) < Wo) shift++;
+  const int TH = 256 / Wo;
+  int dhmin = 1 << 20, dhmax = -(1 << 20), dwmin = 1 << 20, dwmax = -(1 << 20);
+  for (int t = 0; t < q.ntaps; t++) {
+    const int dh = p.dh[q.tap0 + t], dw = p.dw[q.tap0 + t];
+    dhmin = dh < dhmin ? dh : dhmin; dhmax = dh > dhmax ? dh : dhmax;
+    dwmin = dw < dwmin ? dw : dwmin; dwmax = dw > dwmax ? dw : dwmax;
+  }
+  const int PH = TH + dhmax - dhmin, PW = Wo + dwmax - dwmin;
+  if (PH * PW > MT_PP_PCAP) return -1;
+  const int npp = (PH * PW + 15) / 16, nmine = (npp + 7) / 8;
+  if (q.ntaps < nmine + 3) return -1;          // (the next slice's patch must be out three steps before the slice ends)
+  if (p.x_bytes >= 0x7f000000u || q.w_bytes >= 0x3f000000u) return -1;
+  hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+  MT_LAUNCH_CHECK();
+  __atomic_fetch_add(&g_pp_launches, 1, __ATOMIC_RELAXED);
+  return 0;
+}
+template int launch_igemm_pipe_patch_t<true>(IgemmParams&, int, hipStream_t);
+template int launch_igemm_pipe_patch_t<false>(IgemmParams&, int, hipStream_t);

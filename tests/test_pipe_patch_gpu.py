@@ -1,0 +1,82 @@
+"""The 256x256 ping-pong gather-GEMM with a patch-resident pixel operand (csrc/conv_pipe_patch_kernel.hip) against the
+ring kernel it replaces (csrc/conv_pipe_kernel.hip) -- BIT FOR BIT: both walk K slice-major with the taps of a slice
+back to back and accumulate the same MFMA fragments in the same order; only the way the pixel fragment reaches LDS
+differs (one patch copy per slice instead of one tile copy per tap) -- and against the fp32 CPU reference.
+
+Shapes: the residual-block convolution of the step (3x3 256->256 on 64x64, reflection padding: forward, forward with
+fused statistics, interior of the data gradient), the same on 32x32 / 16x16 / 128x128 maps (8, 16, 2 tile rows), two
+weight tiles (512 output channels), 5x5 taps, zero padding, fp32 storage."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_persist_gpu import case_seed, check_against_reference
+
+pytestmark = pytest.mark.gpu
+
+# name, N, Ci, H, W, Co, k, pad, pad_mode, act, dtype
+CASES = [
+    ("k1_64x64", 16, 256, 64, 64, 256, 3, 1, "reflect", None, "bf16"),
+    ("k1_64x64_relu_N32", 32, 256, 64, 64, 256, 3, 1, "reflect", "relu", "bf16"),
+    ("k1_32x32_N64", 64, 256, 32, 32, 256, 3, 1, "reflect", None, "bf16"),
+    ("k1_16x16_zero", 256, 64, 16, 16, 256, 3, 1, "zero", "lrelu", "bf16"),
+    ("k1_128x128_co512", 6, 32, 128, 128, 512, 3, 1, "reflect", None, "bf16"),
+    ("k5_64x64", 16, 64, 64, 64, 256, 5, 2, "reflect", None, "bf16"),
+    ("k1_64x64_fp32", 16, 64, 64, 64, 256, 3, 1, "reflect", None, "fp32"),
+]
+
+
+def _run(ops, lib, case, dev, stats):
+    name, N, Ci, H, W, Co, k, pad, pad_mode, act, dtype = case
+    g = torch.Generator().manual_seed(case_seed(name))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, k, k, generator=g) * (Ci * k * k) ** -0.5).bfloat16().float()
+    xd = x.to(dev).requires_grad_()
+    wd = w.to(dev).requires_grad_()
+    n0 = lib.mt_kernel_variant_launches(3)
+    out = ops.conv2d(xd, wd, None, stride=1, pad=pad, pad_mode=pad_mode, act=act, stats=stats)
+    y, sums = out if stats else (out, None)
+    n1 = lib.mt_kernel_variant_launches(3)
+    gy = torch.randn(*y.shape, generator=g).bfloat16().float()
+    y.backward(gy.to(dev))
+    n2 = lib.mt_kernel_variant_launches(3)
+    return (x, w, gy), (y.detach().float().cpu(), xd.grad.detach().float().cpu(),
+                        None if sums is None else sums.detach().float().cpu()), (n1 - n0, n2 - n1)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_patch_resident_ping_pong_is_bit_identical_to_the_ring_kernel(case, hip_device):
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    dtype = torch.bfloat16 if case[10] == "bf16" else torch.float32
+    ops.set_compute_dtype(dtype)
+    lib = L.load()
+    stats = case[9] is None and dtype == torch.bfloat16          # the fused-statistics epilogue needs act == none
+    prev = lib.mt_kernel_variant_enable(3, 1)
+    try:
+        (x, w, gy), (y1, dx1, s1), used = _run(ops, lib, case, hip_device, stats)
+        # forward on the new kernel; the data gradient too where dx has a multiple of 256 channels (its interior launch)
+        assert used[0] == 1, f"forward launches on the patch-resident kernel: {used[0]}"
+        assert used[1] == (1 if (case[2] % 256 == 0 and case[8] == "reflect") or (case[2] % 256 == 0 and case[8] == "zero") else 0), used
+        lib.mt_kernel_variant_enable(3, 0)
+        _, (y0, dx0, s0), unused = _run(ops, lib, case, hip_device, stats)
+        assert unused == (0, 0)
+    finally:
+        lib.mt_kernel_variant_enable(3, prev)
+        ops.set_compute_dtype(torch.bfloat16)
+    assert torch.equal(y1, y0), f"forward differs from the ring kernel: max {(y1 - y0).abs().max().item():.3e}"
+    assert torch.equal(dx1, dx0), f"data gradient differs from the ring kernel: max {(dx1 - dx0).abs().max().item():.3e}"
+    if stats:
+        # (the statistics are accumulated with float atomics: equal up to their order)
+        assert torch.allclose(s1, s0, rtol=1e-4, atol=1e-3), (s1 - s0).abs().max()
+    if 2.0 * case[1] * case[3] * case[4] * case[2] * case[5] * case[6] ** 2 > 1e11:
+        return          # (a CPU reference of this size takes minutes; the ring kernel it equals bit for bit is checked at this size
+                        #  through the adjoint identities of tests/test_fullsize_gpu.py)
+    if dtype == torch.bfloat16:
+        name, N, Ci, H, W, Co, k, pad, pad_mode, act, _ = case
+        check_against_reference((name, "conv", N, Ci, H, W, Co, k, 1, pad, pad_mode, False, act), x, w, None, gy, y1, dx1)
+    else:
+        xr = x.clone().requires_grad_()
+        yr = F.conv2d(F.pad(xr, (case[7],) * 4, mode="reflect"), w)
+        yr.backward(gy)
+        assert ((y1 - yr.detach()).norm() / yr.detach().norm()).item() < 1e-5
+        assert ((dx1 - xr.grad).norm() / xr.grad.norm()).item() < 1e-5
