@@ -493,6 +493,13 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
     p.y = (char*)dx; p.Hout = d->H; p.Wout = d->W;
     phase(0, 0, 0, d->H, d->W);
     for (int t = 0; t < p.ph[0].ntaps; t++) { p.dh[t] = (short)(p.dh[t] + P); p.dw[t] = (short)(p.dw[t] + P); }
+    // 3x3, pad 1 on the patch-resident 256x256 kernel: the reflected ring is added inside the pixel operand -- one
+    // launch, no ring GEMM, no workspace, no fold (conv_pipe_patch_kernel.hip)
+    if (P == 1 && d->kh == 3 && d->kw == 3) {
+      p.fold = 1;
+      if (mt_igemm_fold_ok(d->dtype, p)) return mt_launch_igemm(d->dtype, p, s) ? 2 : 0;
+      p.fold = 0;
+    }
     if (mt_launch_igemm(d->dtype, p, s)) return 2;
     // (2) the four strips of the ring, into the padded workspace
     p.nphase = 0;

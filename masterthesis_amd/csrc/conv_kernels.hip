@@ -429,7 +429,7 @@ int launch_igemm_pipe_t(IgemmParams& p, int WT, int PT, int total, hipStream_t s
 int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool dry);          // conv_persist_kernel.hip
 int launch_igemm_patch(IgemmParams& p, hipStream_t s, bool dry);                                // conv_patch_kernel.hip
 template <bool BF16>
-int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s);                         // conv_pipe_patch_kernel.hip
+int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry);               // conv_pipe_patch_kernel.hip
 
 // dry: launch nothing; return 100 if a kernel that honours IgemmParams::y2 (persistent / patch-resident) would take the problem, 101 otherwise
 template <bool BF16>
@@ -489,10 +489,15 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
   }
   if (total == 0) return dry ? 101 : 0;
   // 256x256 and 128x512 tiles run the ping-pong pipelined kernel (conv_pipe_kernel.hip)
-  if (PT == 256 && WT == 256 && !dry) {
+  if (PT == 256 && WT == 256) {
     // ... with the pixel operand resident in LDS as a patch where the map allows it (conv_pipe_patch_kernel.hip)
-    const int r = launch_igemm_pipe_patch_t<BF16>(p, total, s);
+    const int r = launch_igemm_pipe_patch_t<BF16>(p, total, s, dry);
     if (r >= 0) return r;
+  }
+  if (p.fold) {
+    if (dry) return 101;
+    mt_set_error("igemm: the in-operand reflection fold needs the patch-resident 256x256 kernel (mt_igemm_fold_ok)");
+    return 1;
   }
   if (PT >= 256) return dry ? 101 : launch_igemm_pipe_t<BF16>(p, WT, PT, total, s);
   // launches that do not fill the chip (latency-bound k loops): the 4-wave ring variant
@@ -644,6 +649,13 @@ int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s) {
   }
   MT_CHECK(q.y2 == nullptr || mt_igemm_would_persist(dtype, p), "igemm: a second destination needs the persistent kernel");
   return dtype == MT_BF16 ? launch_igemm_t<true>(q, s) : launch_igemm_t<false>(q, s);
+}
+bool mt_igemm_fold_ok(int dtype, const IgemmParams& p) {
+  if (p.nphase != 1 || p.cpc < 1 || !p.fold || (double)p.N * p.Hi * p.Wi * p.Cib >= 4294967000.0) return false;
+  IgemmParams q = p;
+  q.x_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cib);
+  q.korder = 1;
+  return (dtype == MT_BF16 ? launch_igemm_t<true>(q, nullptr, true) : launch_igemm_t<false>(q, nullptr, true)) == 102;
 }
 bool mt_igemm_would_persist(int dtype, const IgemmParams& p) {
   if (dtype != MT_BF16 || p.nphase < 1 || p.cpc < 1) return false;

@@ -53,6 +53,8 @@ struct IgemmParams {
   char* y2;           // optional second destination (persistent gather-GEMM only, mt_igemm_would_persist): output pixels
   int y2P, y2H, y2W;  // inside [y2P, y2P+y2H) x [y2P, y2P+y2W) of the (Hout, Wout) grid go to y2 -- an [N][y2H][y2W][Co] tensor,
                       // at (oh - y2P, ow - y2P) -- instead of y: the interior of a padded gradient map straight into dx
+  int fold;           // stride-1 3x3 gather over dy at offsets -1 .. 1 (the interior of a reflection-padded data gradient): also
+                      // add the reflected ring inside the pixel operand (conv_pipe_patch_kernel.hip; mt_igemm_fold_ok)
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements
                       // whatever the storage type); mt_launch_splitk_finish sums the slabs
   short dh[MT_MAX_TAPS];
@@ -88,6 +90,8 @@ struct PackParams {
 };
 
 int mt_launch_igemm(int dtype, const IgemmParams& p, hipStream_t s);
+// would mt_launch_igemm run this problem (IgemmParams::fold set) on the kernel that folds inside the operand?
+bool mt_igemm_fold_ok(int dtype, const IgemmParams& p);
 // would mt_launch_igemm run this problem on the persistent kernel (the only one that honours IgemmParams::y2)?
 bool mt_igemm_would_persist(int dtype, const IgemmParams& p);
 // y[i] = act(sum_s slabs[s][i] + bias[i % Cp])  (i over `total` NHWC elements, fp32 slabs, output in `dtype`)

@@ -13,6 +13,15 @@
 // issues 2 weight copies plus at most one patch copy in 4 of 9 steps, instead of 4 copies; the gather-offset table is
 // gone (the patch rows carry reflection / zero padding, resolved once per tile).
 //
+// FOLD (the data gradient of a reflection-padded 3x3 stride-1 convolution, pad 1, in ONE launch): dx = fold(dxp) adds the
+// border ring of the padded-grid gradient back onto the pixels it was reflected from.  Written out per tap (a, b), with
+// (dh, dw) = (1 - a, 1 - b) the offset at which dx[u][v] reads dy: the reflected contributions are reads at the MIRRORED
+// offsets -- (-dh, dw) for the rows u = 1 (a = 0) and u = H-2 (a = 2), (dh, -dw) for the columns v = 1 (b = 0) and
+// v = W-2 (b = 2), (-dh, -dw) where both hold -- multiplied with the SAME weight tap.  All four positions are inside
+// the resident patch, so the fold is a sum of up to four patch reads in the pixel fragment (bf16: one extra rounding
+// of the summed operand on those pixels; fp32: exact up to summation order) in 6 of 36 fragment-taps of a wave, and
+// the ring GEMM (23 us of latency), the workspace and the fold kernel of the interior + ring scheme go away.
+//
 // Everything else is igemm_pipe_kernel: 8 waves = two groups of four in ping-pong (memory phase / 32 MFMAs), 4-stage
 // weight ring with a counted s_waitcnt vmcnt, permuted weight rows for 16-byte epilogue stores, fused per-(image,
 // channel) statistics.  The count of copies per step varies (2 or 3), so the wait picks one of three immediates.
@@ -23,6 +32,17 @@ constexpr int MT_PP_PCAP = 544;          // rows of a patch slot (4 x 130 for 12
 constexpr int MT_PP_MAXTAPS = 25;
 
 template <bool BF16>
+__device__ __forceinline__ u32x4 pp_add_chunk(const u32x4& a, const u32x4& b) {
+  constexpr int V = Elem<BF16>::V;
+  float fa[V], fb[V];
+  Elem<BF16>::unpack(a, fa);
+  Elem<BF16>::unpack(b, fb);
+#pragma unroll
+  for (int e = 0; e < V; e++) fa[e] += fb[e];
+  return Elem<BF16>::pack(fa);
+}
+
+template <bool BF16, bool FOLD>
 __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams p, const int PH, const int PW, const int dh0,
                                                                const int dw0, const int wo_shift) {
   constexpr int WT = 256, PT = 256, NT = 512, NS = 4, NW = 8;
@@ -34,12 +54,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   constexpr int NPW = (PCAP / 16 + NW - 1) / NW;       // patch copies per wave per slice (at most)
   constexpr unsigned OOB = 0x80000000u;
   static_assert(NPW <= 5, "literal-sized arrays");
-  static_assert((NS * STAGE + 2 * PCAP * 4) * 16 + 32 * 4 <= 160 * 1024, "LDS budget");
+  static_assert((NS * STAGE + 2 * PCAP * 4) * 16 + 160 * 4 <= 160 * 1024, "LDS budget");
 
   // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt)
-  __shared__ u32x4 smem[NS * STAGE + 2 * PCAP * 4 + 8];
+  __shared__ u32x4 smem[NS * STAGE + 2 * PCAP * 4 + 40];
   u32x4* const sP = smem + NS * STAGE;
-  int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);        // [<= 25 (+ pad)] patch row offset per tap
+  // [0..31] patch row offset per tap; FOLD: [32..63] row-mirrored, [64..95] column-mirrored, [96..127] both, [128..159] (dh+1) | (dw+1) << 2
+  int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -57,7 +78,16 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   const int nsl = p.cpc >> 2;                  // 64-byte channel slices
   const int nk = ntaps * nsl;
 
-  if (tid < 32) sQ[tid] = tid < ntaps ? ((int)p.dh[ph.tap0 + tid] - dh0) * PW + ((int)p.dw[ph.tap0 + tid] - dw0) : 0;
+  if (tid < 32) {
+    const int dh = tid < ntaps ? (int)p.dh[ph.tap0 + tid] : 0, dw = tid < ntaps ? (int)p.dw[ph.tap0 + tid] : 0;
+    sQ[tid] = tid < ntaps ? (dh - dh0) * PW + (dw - dw0) : 0;
+    if constexpr (FOLD) {
+      sQ[32 + tid] = (-dh - dh0) * PW + (dw - dw0);
+      sQ[64 + tid] = (dh - dh0) * PW + (-dw - dw0);
+      sQ[96 + tid] = (-dh - dh0) * PW + (-dw - dw0);
+      sQ[128 + tid] = (dh + 1) | ((dw + 1) << 2);
+    }
+  }
 
   // ---- the tile: 256 consecutive pixels of one image = TH full rows (host: 256 % Wo == 0, HoWo % 256 == 0) ----
   const int m0 = pt * PT;
@@ -96,6 +126,21 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   for (int b = 0; b < FP; b++) {
     const int tp = wpI * WP + b * 16 + fr;
     q0[b] = (tp >> wo_shift) * PW + (tp & (ph_Wo - 1));
+  }
+
+  // FOLD: which fragments hold the rows / columns that receive reflected contributions (wave-uniform per fragment), and
+  // which lane holds the column
+  bool f_rT[FP], f_rB[FP], f_hasL[FP], f_hasR[FP], f_cL[FP], f_cR[FP];
+#pragma unroll
+  for (int b = 0; b < FP; b++) {
+    const int tpb = wpI * WP + b * 16;                   // (uniform: 16 divides the map width)
+    const int u = ho0 + (tpb >> wo_shift), c0 = tpb & (ph_Wo - 1);
+    f_rT[b] = FOLD && u == 1;
+    f_rB[b] = FOLD && u == p.Hi - 2;
+    f_hasL[b] = FOLD && c0 == 0;
+    f_hasR[b] = FOLD && c0 + 16 == ph_Wo;
+    f_cL[b] = FOLD && (c0 + fr) == 1;
+    f_cR[b] = FOLD && (c0 + fr) == ph_Wo - 2;
   }
 
   // ---- weight staging (as in igemm_pipe_kernel) ----
@@ -191,6 +236,33 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
       for (int b = 0; b < FP; b++) {
         const int q = q0[b] + qo;
         xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
+      }
+      if constexpr (FOLD) {
+        const int code = sQ[128 + tap_c];
+        const int dhs = (code & 3) - 1, dws = ((code >> 2) & 3) - 1;
+        if (dhs != 0 || dws != 0) {
+          const int qr = sQ[32 + tap_c], qc = sQ[64 + tap_c], qrc = sQ[96 + tap_c];
+#pragma unroll
+          for (int b = 0; b < FP; b++) {
+            const bool rh = dhs > 0 ? f_rT[b] : (dhs < 0 ? f_rB[b] : false);          // wave-uniform
+            const bool ch = dws > 0 ? f_hasL[b] : (dws < 0 ? f_hasR[b] : false);      // wave-uniform
+            if (rh) {
+              const int q = q0[b] + qr;
+              xf[b] = pp_add_chunk<BF16>(xf[b], sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
+            }
+            if (ch) {
+              const bool cl = dws > 0 ? f_cL[b] : f_cR[b];                              // this lane's pixel is the column
+              int q = q0[b] + qc;
+              u32x4 t = pp_add_chunk<BF16>(xf[b], sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
+              if (rh) {
+                q = q0[b] + qrc;
+                t = pp_add_chunk<BF16>(t, sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; e++) xf[b][e] = cl ? t[e] : xf[b][e];
+            }
+          }
+        }
       }
     }
     tap_c++;
@@ -314,9 +386,9 @@ int mt_pipe_patch_enable(int on) {
   return prev;
 }
 
-// -> 0 launched, 1 error, -1 not this kernel's shape (the caller launches igemm_pipe_kernel)
+// -> 0 launched, 1 error, -1 not this kernel's shape (the caller launches igemm_pipe_kernel); dry: 102 = would launch
 template <bool BF16>
-int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s) {
+int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry) {
   if (!pp_enabled()) return -1;
   const IgemmPhase& q = p.ph[0];
   if (p.nphase != 1 || p.raw || p.is != 1 || p.cpc % 4 != 0 || p.CoRows % 256 != 0) return -1;
@@ -337,10 +409,20 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s) {
   const int npp = (PH * PW + 15) / 16, nmine = (npp + 7) / 8;
   if (q.ntaps < nmine + 3) return -1;          // (the next slice's patch must be out three steps before the slice ends)
   if (p.x_bytes >= 0x7f000000u || q.w_bytes >= 0x3f000000u) return -1;
-  hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+  if (p.fold) {
+    // the in-operand fold is written for a 3x3 window at offsets -1 .. 1 on a map of the output's size (pad 1)
+    if (q.ntaps != 9 || dhmin != -1 || dhmax != 1 || dwmin != -1 || dwmax != 1 || p.Hi < 4 || p.Wi < 4 || p.Hi != Ho || p.Wi != Wo ||
+        p.pad_mode != MT_PAD_ZERO || p.os != 1 || p.stats != nullptr)
+      return -1;
+  }
+  if (dry) return 102;
+  if (p.fold)
+    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, true>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+  else
+    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, false>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_pp_launches, 1, __ATOMIC_RELAXED);
   return 0;
 }
-template int launch_igemm_pipe_patch_t<true>(IgemmParams&, int, hipStream_t);
-template int launch_igemm_pipe_patch_t<false>(IgemmParams&, int, hipStream_t);
+template int launch_igemm_pipe_patch_t<true>(IgemmParams&, int, hipStream_t, bool);
+template int launch_igemm_pipe_patch_t<false>(IgemmParams&, int, hipStream_t, bool);
