@@ -10,6 +10,7 @@
 #include "mt_common.h"
 #include "conv_params.h"
 #include <string.h>
+#include <stdlib.h>
 
 static inline int esz(int dtype) { return dtype == MT_BF16 ? 2 : 4; }
 static inline int vec(int dtype) { return 16 / esz(dtype); }
@@ -495,7 +496,8 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
     for (int t = 0; t < p.ph[0].ntaps; t++) { p.dh[t] = (short)(p.dh[t] + P); p.dw[t] = (short)(p.dw[t] + P); }
     // 3x3, pad 1 on the patch-resident 256x256 kernel: the reflected ring is added inside the pixel operand -- one
     // launch, no ring GEMM, no workspace, no fold (conv_pipe_patch_kernel.hip)
-    if (P == 1 && d->kh == 3 && d->kw == 3) {
+    static const int fold_on = getenv("MT_IGEMM_FOLD") ? atoi(getenv("MT_IGEMM_FOLD")) : 1;
+    if (fold_on && P == 1 && d->kh == 3 && d->kw == 3) {
       p.fold = 1;
       if (mt_igemm_fold_ok(d->dtype, p)) return mt_launch_igemm(d->dtype, p, s) ? 2 : 0;
       p.fold = 0;

@@ -17,10 +17,15 @@
 // border ring of the padded-grid gradient back onto the pixels it was reflected from.  Written out per tap (a, b), with
 // (dh, dw) = (1 - a, 1 - b) the offset at which dx[u][v] reads dy: the reflected contributions are reads at the MIRRORED
 // offsets -- (-dh, dw) for the rows u = 1 (a = 0) and u = H-2 (a = 2), (dh, -dw) for the columns v = 1 (b = 0) and
-// v = W-2 (b = 2), (-dh, -dw) where both hold -- multiplied with the SAME weight tap.  All four positions are inside
-// the resident patch, so the fold is a sum of up to four patch reads in the pixel fragment (bf16: one extra rounding
-// of the summed operand on those pixels; fp32: exact up to summation order) in 6 of 36 fragment-taps of a wave, and
-// the ring GEMM (23 us of latency), the workspace and the fold kernel of the interior + ring scheme go away.
+// v = W-2 (b = 2), (-dh, -dw) where both hold -- multiplied with the SAME weight tap, so the fold is a sum of up to four
+// patch cells in the pixel operand.  Those sums are built ONCE per slice as virtual cells behind the patch rows
+// (VL[i] = P[i][0] + P[i][2] and VR per patch row; in the tiles that hold row 1 or H-2 also VT[j] = P[0][j] + P[2][j], VB
+// and their corner cells; waves 0-3 do it in the memory phase of step 6 of the previous slice, when every wave's patch
+// copies have landed), and in the main loop the affected lanes only read another address: no extra LDS read, no
+// arithmetic beside the MFMAs.  (A first version added the mirrored cells in the memory phase -- dependent LDS reads
+// and ~45 VALU per fragment-tap -- and ran 137 us against 101 us for interior + ring + fold: the memory phase must
+// stay shorter than the partner group's 32 MFMAs.)  bf16: one extra rounding of the summed operand on those pixels;
+// fp32: exact up to summation order.  The ring GEMM (23 us of latency), the workspace and the fold kernel go away.
 //
 // Everything else is igemm_pipe_kernel: 8 waves = two groups of four in ping-pong (memory phase / 32 MFMAs), 4-stage
 // weight ring with a counted s_waitcnt vmcnt, permuted weight rows for 16-byte epilogue stores, fused per-(image,
@@ -28,7 +33,7 @@
 #include "conv_device.h"
 #include <stdlib.h>
 
-constexpr int MT_PP_PCAP = 544;          // rows of a patch slot (4 x 130 for 128-wide maps, 8 x 68 for 5x5 taps on 64-wide ones)
+constexpr int MT_PP_PCAP = 560;          // rows of a patch slot (4 x 130 for 128-wide maps, 8 x 68 for 5x5 taps on 64-wide ones)
 constexpr int MT_PP_MAXTAPS = 25;
 
 template <bool BF16>
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt)
   __shared__ u32x4 smem[NS * STAGE + 2 * PCAP * 4 + 40];
   u32x4* const sP = smem + NS * STAGE;
-  // [0..31] patch row offset per tap; FOLD: [32..63] row-mirrored, [64..95] column-mirrored, [96..127] both, [128..159] (dh+1) | (dw+1) << 2
+  // [0..31] patch row offset per tap; FOLD: [128..159] (dh+1) | (dw+1) << 2
   int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);
 
   const int tid = threadIdx.x;
@@ -81,12 +86,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   if (tid < 32) {
     const int dh = tid < ntaps ? (int)p.dh[ph.tap0 + tid] : 0, dw = tid < ntaps ? (int)p.dw[ph.tap0 + tid] : 0;
     sQ[tid] = tid < ntaps ? (dh - dh0) * PW + (dw - dw0) : 0;
-    if constexpr (FOLD) {
-      sQ[32 + tid] = (-dh - dh0) * PW + (dw - dw0);
-      sQ[64 + tid] = (dh - dh0) * PW + (-dw - dw0);
-      sQ[96 + tid] = (-dh - dh0) * PW + (-dw - dw0);
-      sQ[128 + tid] = (dh + 1) | ((dw + 1) << 2);
-    }
+    if constexpr (FOLD) sQ[128 + tid] = (dh + 1) | ((dw + 1) << 2);
   }
 
   // ---- the tile: 256 consecutive pixels of one image = TH full rows (host: 256 % Wo == 0, HoWo % 256 == 0) ----
@@ -130,11 +130,20 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
 
   // FOLD: which fragments hold the rows / columns that receive reflected contributions (wave-uniform per fragment), and
   // which lane holds the column
+  // virtual cells of a patch slot (FOLD), as patch rows behind the real ones:
+  //   VL[i] = prows + i, VR[i] = prows + PH + i              (i = patch row)
+  //   VT[j] = prows + 2 PH + j, then VT_L, VT_R;  VB[j] = prows + 2 PH + PW + 2 + j, then VB_L, VB_R   (j = patch column)
+  const int vL0 = prows, vR0 = prows + PH, vT0 = prows + 2 * PH, vB0 = prows + 2 * PH + PW + 2;
+  const bool tileT = FOLD && ho0 <= 1 && 1 < ho0 + (PT >> wo_shift);                       // the tile holds row 1 / row H-2
+  const bool tileB = FOLD && ho0 <= p.Hi - 2 && p.Hi - 2 < ho0 + (PT >> wo_shift);
   bool f_rT[FP], f_rB[FP], f_hasL[FP], f_hasR[FP], f_cL[FP], f_cR[FP];
+  int f_ly[FP], f_lx[FP];
 #pragma unroll
   for (int b = 0; b < FP; b++) {
     const int tpb = wpI * WP + b * 16;                   // (uniform: 16 divides the map width)
     const int u = ho0 + (tpb >> wo_shift), c0 = tpb & (ph_Wo - 1);
+    f_ly[b] = tpb >> wo_shift;
+    f_lx[b] = c0 + fr;
     f_rT[b] = FOLD && u == 1;
     f_rB[b] = FOLD && u == p.Hi - 2;
     f_hasL[b] = FOLD && c0 == 0;
@@ -183,6 +192,46 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
                                              off + (unsigned)sl * 64u, 0, 0, 0);
   };
 
+  // FOLD: the virtual cells of patch slot `pslot` (its copies have landed and are visible), by the 256 threads of one
+  // wave group: task = (cell, 16-byte chunk)
+  auto cell_addr = [&](int row, int chunk) { return row * 4 + (chunk ^ ((row >> 1) & 3)); };
+  auto build_virtual = [&](int pslot) {
+    u32x4* const P = sP + pslot * (PCAP * 4);
+    const int t = tid & 255;
+    const int chunk = t & 3;
+    const int iT0 = 1 - ho0 - dh0 - 1, iT2 = iT0 + 2;                  // patch rows of dy rows 0 and 2
+    const int iB0 = (p.Hi - 1) - ho0 - dh0, iB2 = iB0 - 2;              // ... of dy rows H-1 and H-3
+    const int jL0 = 0 - dw0, jL2 = 2 - dw0, jR0 = (ph_Wo - 1) - dw0, jR2 = (ph_Wo - 3) - dw0;    // patch columns of dy columns 0, 2, W-1, W-3
+    const int ncell = 2 * PH + ((tileT || tileB) ? 2 * (PW + 2) : 0);
+    for (int c = t >> 2; c < ncell; c += 64) {
+      int dst, a0, a1, a2 = -1, a3 = -1;
+      if (c < 2 * PH) {
+        const bool right = c >= PH;
+        const int i = right ? c - PH : c;
+        dst = (right ? vR0 : vL0) + i;
+        a0 = i * PW + (right ? jR0 : jL0);
+        a1 = i * PW + (right ? jR2 : jL2);
+      } else {
+        const int cc = c - 2 * PH;
+        const bool bot = cc >= PW + 2;
+        const int j = bot ? cc - (PW + 2) : cc;
+        if ((bot && !tileB) || (!bot && !tileT)) continue;
+        const int r0 = bot ? iB0 : iT0, r2 = bot ? iB2 : iT2;
+        dst = (bot ? vB0 : vT0) + j;
+        if (j < PW) {
+          a0 = r0 * PW + j;
+          a1 = r2 * PW + j;
+        } else {                                  // corner cells: columns {0, 2} (j == PW) or {W-1, W-3} (j == PW + 1) of both rows
+          const int c0 = j == PW ? jL0 : jR0, c2 = j == PW ? jL2 : jR2;
+          a0 = r0 * PW + c0; a1 = r2 * PW + c0; a2 = r0 * PW + c2; a3 = r2 * PW + c2;
+        }
+      }
+      u32x4 v = pp_add_chunk<BF16>(P[cell_addr(a0, chunk)], P[cell_addr(a1, chunk)]);
+      if (a2 >= 0) v = pp_add_chunk<BF16>(v, pp_add_chunk<BF16>(P[cell_addr(a2, chunk)], P[cell_addr(a3, chunk)]));
+      P[cell_addr(dst, chunk)] = v;
+    }
+  };
+
   f32x4 acc[FC][FP];
 #pragma unroll
   for (int a = 0; a < FC; a++)
@@ -195,6 +244,10 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   for (int s = 0; s < NS - 1; s++) issue_weights(s);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NWL) : "memory");
   __syncthreads();              // sQ visible; every wave's patch rows and stage 0 have landed
+  if constexpr (FOLD) {
+    if (tid < 256) build_virtual(0);
+    __syncthreads();
+  }
 
   // ---- ping-pong main loop (see igemm_pipe_kernel): waves 0-3 and 4-7 alternate between a MEMORY phase (copies of
   // stage ks+NS-1 and of the next slice's patch, fragment reads of stage ks) and a COMPUTE phase (32 MFMAs) ----
@@ -232,38 +285,38 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
         const int row = wcI * WC + a * 16 + fr;
         wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
       }
-#pragma unroll
-      for (int b = 0; b < FP; b++) {
-        const int q = q0[b] + qo;
-        xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
-      }
       if constexpr (FOLD) {
         const int code = sQ[128 + tap_c];
         const int dhs = (code & 3) - 1, dws = ((code >> 2) & 3) - 1;
-        if (dhs != 0 || dws != 0) {
-          const int qr = sQ[32 + tap_c], qc = sQ[64 + tap_c], qrc = sQ[96 + tap_c];
+        int qq[FP];
 #pragma unroll
-          for (int b = 0; b < FP; b++) {
-            const bool rh = dhs > 0 ? f_rT[b] : (dhs < 0 ? f_rB[b] : false);          // wave-uniform
-            const bool ch = dws > 0 ? f_hasL[b] : (dws < 0 ? f_hasR[b] : false);      // wave-uniform
-            if (rh) {
-              const int q = q0[b] + qr;
-              xf[b] = pp_add_chunk<BF16>(xf[b], sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
-            }
-            if (ch) {
-              const bool cl = dws > 0 ? f_cL[b] : f_cR[b];                              // this lane's pixel is the column
-              int q = q0[b] + qc;
-              u32x4 t = pp_add_chunk<BF16>(xf[b], sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
-              if (rh) {
-                q = q0[b] + qrc;
-                t = pp_add_chunk<BF16>(t, sPs[q * 4 + (fg ^ ((q >> 1) & 3))]);
-              }
-#pragma unroll
-              for (int e = 0; e < 4; e++) xf[b][e] = cl ? t[e] : xf[b][e];
-            }
+        for (int b = 0; b < FP; b++) {
+          int q = q0[b] + qo;
+          const bool rh = dhs > 0 ? f_rT[b] : (dhs < 0 ? f_rB[b] : false);          // wave-uniform
+          const bool ch = dws > 0 ? f_hasL[b] : (dws < 0 ? f_hasR[b] : false);      // wave-uniform
+          const int vrow = dhs > 0 ? vT0 : vB0;
+          if (rh) q = vrow + f_lx[b] + dws + 1;                                     // VT / VB cell of column v + dw
+          if (ch) {
+            const bool cl = dws > 0 ? f_cL[b] : f_cR[b];                            // this lane's pixel is the column
+            const int alt = rh ? vrow + PW + (dws > 0 ? 0 : 1) : (dws > 0 ? vL0 : vR0) + f_ly[b] + dhs + 1;
+            q = cl ? alt : q;
           }
+          qq[b] = q;
+        }
+#pragma unroll
+        for (int b = 0; b < FP; b++) xf[b] = sPs[qq[b] * 4 + (fg ^ ((qq[b] >> 1) & 3))];
+      } else {
+#pragma unroll
+        for (int b = 0; b < FP; b++) {
+          const int q = q0[b] + qo;
+          xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
         }
       }
+    }
+    if constexpr (FOLD) {
+      // virtual cells of the NEXT slice's patch: all of its copies were issued in steps 0 .. 3 of this slice and have
+      // landed, for every wave, once group 0 enters step 6
+      if (tap_c == 6 && grp == 0 && sl_c + 1 < nsl) build_virtual((sl_c + 1) & 1);
     }
     tap_c++;
     if (tap_c == ntaps) { tap_c = 0; sl_c++; p_j = 0; }
@@ -414,6 +467,8 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
     if (q.ntaps != 9 || dhmin != -1 || dhmax != 1 || dwmin != -1 || dwmax != 1 || p.Hi < 4 || p.Wi < 4 || p.Hi != Ho || p.Wi != Wo ||
         p.pad_mode != MT_PAD_ZERO || p.os != 1 || p.stats != nullptr)
       return -1;
+    // the virtual cells live behind the patch rows; the next slice's copies must all be out by step 3 (they are built in step 6)
+    if (PH * PW + 2 * PH + 2 * (PW + 2) > MT_PP_PCAP || nmine > 4) return -1;
   }
   if (dry) return 102;
   if (p.fold)
