@@ -32,6 +32,7 @@
 // channel) statistics.  The count of copies per step varies (2 or 3), so the wait picks one of three immediates.
 #include "conv_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 constexpr int MT_PP_PCAP = 560;          // rows of a patch slot (4 x 130 for 128-wide maps, 8 x 68 for 5x5 taps on 64-wide ones)
 constexpr int MT_PP_MAXTAPS = 25;
@@ -47,7 +48,24 @@ __device__ __forceinline__ u32x4 pp_add_chunk(const u32x4& a, const u32x4& b) {
   return Elem<BF16>::pack(fa);
 }
 
-template <bool BF16, bool FOLD>
+// acc += a x b with the accumulator tied to ONE register quad.  (In the nine-step unrolled body hipcc otherwise writes every
+// MFMA's result to a fresh quad -- v[2:5] = mfma(.., v[126:129]) -- and the rotating accumulators push 113 values into
+// scratch, whose reloads are vector-memory operations with a vmcnt(0) in front: the LDS-DMA queue drains.)
+template <bool BF16>
+__device__ __forceinline__ void mma_inplace(f32x4& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (BF16) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; s++) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a[s]), "v"(b[s]));
+  }
+}
+
+// TAPS9: nine taps (every 3x3 layer): the slice's nine steps are unrolled and the LDS address of every (tap, fragment)
+// pair -- FOLD redirections included -- is computed once per tile into 36 registers.  A vector instruction in the memory
+// phase waits for an issue slot beside the partner wave's prioritised MFMAs (~16 cycles each: 30 of them made the first
+// FOLD version 35 % slower); with the addresses resident the memory phase is copies + LDS reads only.
+template <bool BF16, bool FOLD, bool TAPS9>
 __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams p, const int PH, const int PW, const int dh0,
                                                                const int dw0, const int wo_shift) {
   constexpr int WT = 256, PT = 256, NT = 512, NS = 4, NW = 8;
@@ -56,15 +74,16 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   constexpr int NWL = 2;                       // weight copies per wave per stage
   constexpr int STAGE = WT * 4;                // u32x4 per weight stage (256 rows x 64 B)
   constexpr int PCAP = MT_PP_PCAP;
-  constexpr int NPW = (PCAP / 16 + NW - 1) / NW;       // patch copies per wave per slice (at most)
+  constexpr int NPW = FOLD ? 4 : (PCAP / 16 + NW - 1) / NW;       // patch copies per wave per slice (at most; FOLD: host)
   constexpr unsigned OOB = 0x80000000u;
   static_assert(NPW <= 5, "literal-sized arrays");
+  static_assert(TAPS9 || !FOLD, "the in-operand fold is written for the nine-tap loop");
   static_assert((NS * STAGE + 2 * PCAP * 4) * 16 + 160 * 4 <= 160 * 1024, "LDS budget");
 
   // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt)
   __shared__ u32x4 smem[NS * STAGE + 2 * PCAP * 4 + 40];
   u32x4* const sP = smem + NS * STAGE;
-  // [0..31] patch row offset per tap; FOLD: [128..159] (dh+1) | (dw+1) << 2
+  // [0..31] patch row offset per tap (the generic loop; the nine-tap loop keeps its addresses in registers)
   int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);
 
   const int tid = threadIdx.x;
@@ -86,7 +105,6 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   if (tid < 32) {
     const int dh = tid < ntaps ? (int)p.dh[ph.tap0 + tid] : 0, dw = tid < ntaps ? (int)p.dw[ph.tap0 + tid] : 0;
     sQ[tid] = tid < ntaps ? (dh - dh0) * PW + (dw - dw0) : 0;
-    if constexpr (FOLD) sQ[128 + tid] = (dh + 1) | ((dw + 1) << 2);
   }
 
   // ---- the tile: 256 consecutive pixels of one image = TH full rows (host: 256 % Wo == 0, HoWo % 256 == 0) ----
@@ -150,6 +168,33 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     f_hasR[b] = FOLD && c0 + 16 == ph_Wo;
     f_cL[b] = FOLD && (c0 + fr) == 1;
     f_cR[b] = FOLD && (c0 + fr) == ph_Wo - 2;
+  }
+
+  // TAPS9: LDS byte offset (from the start of the shared array, patch slot 0; slot 1 is a constant further, which fits
+  // the DS instruction's 16-bit immediate) of this lane's chunk of fragment b at tap t
+  int qa[9][FP];
+  if constexpr (TAPS9) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int dh = (int)p.dh[ph.tap0 + t], dw = (int)p.dw[ph.tap0 + t];
+      const int qo = (dh - dh0) * PW + (dw - dw0);
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        int q = q0[b] + qo;
+        if constexpr (FOLD) {
+          const bool rh = dh > 0 ? f_rT[b] : (dh < 0 ? f_rB[b] : false);
+          const bool ch = dw > 0 ? f_hasL[b] : (dw < 0 ? f_hasR[b] : false);
+          const int vrow = dh > 0 ? vT0 : vB0;
+          if (rh) q = vrow + f_lx[b] + dw + 1;                                      // VT / VB cell of column v + dw
+          if (ch) {
+            const bool cl = dw > 0 ? f_cL[b] : f_cR[b];                             // this lane's pixel is the column
+            const int alt = rh ? vrow + PW + (dw > 0 ? 0 : 1) : (dw > 0 ? vL0 : vR0) + f_ly[b] + dh + 1;
+            q = cl ? alt : q;
+          }
+        }
+        qa[t][b] = (NS * STAGE + q * 4 + (fg ^ ((q >> 1) & 3))) * 16;
+      }
+    }
   }
 
   // ---- weight staging (as in igemm_pipe_kernel) ----
@@ -258,9 +303,88 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     __builtin_amdgcn_sched_barrier(0);
   }
   int slot = 0;                 // ring slot of stage ks
+  int c_prev = NWL;             // copies issued in the previous memory phase
+  if constexpr (TAPS9) {
+    int sl_c = 0;               // slice being computed
+    // one step: tap T (compile time) of slice sl_c, whose patch sits in slot PAR = sl_c & 1
+    auto step = [&](auto T_c, auto PAR_c) {
+      constexpr int T = decltype(T_c)::value, PAR = decltype(PAR_c)::value;
+      int fill = slot - 1;
+      fill = fill < 0 ? NS - 1 : fill;
+      if constexpr (FOLD && T == 6) {
+        // virtual cells of the NEXT slice's patch: its copies went out in steps 0 .. 3 of this slice and have landed, for
+        // every wave, once group 0 enters step 6 (nmine <= 4 with FOLD: host).  First thing in the step, before the
+        // fragments of this step occupy their registers.
+        if (grp == 0 && sl_c + 1 < nsl) build_virtual(PAR ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      u32x4 wf[FC], xf[FP];
+      int c_now = NWL;
+      if constexpr (T < NPW) {
+        // the next slice's patch: copy T in step T (read three or more steps after the last one, behind the counted wait)
+        if (T < nmine && sl_c + 1 < nsl) {
+          patch_piece(PAR ^ 1, T, sl_c + 1);
+          c_now++;
+        }
+      }
+      issue_weights(fill);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const u32x4* sWs = &smem[slot * STAGE];
+#pragma unroll
+        for (int a = 0; a < FC; a++) {
+          const int row = wcI * WC + a * 16 + fr;
+          wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
+        }
+        static_assert(PCAP * 64 < 65536, "the second patch slot must be reachable through the DS offset field");
+#pragma unroll
+        for (int b = 0; b < FP; b++)
+          xf[b] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(smem) + qa[T][b] + PAR * (PCAP * 64));
+      }
+      {
+        const int young = c_prev + c_now;      // 2 NWL .. 2 NWL + 2
+        if (young == 2 * NWL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL) : "memory");
+        else if (young == 2 * NWL + 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWL + 2) : "memory");
+        c_prev = c_now;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < FC; a++)
+#pragma unroll
+        for (int b = 0; b < FP; b++) mma_inplace<BF16>(acc[a][b], wf[a], xf[b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    };
+#define PP_SLICE(PAR)                                                                                              \
+  do {                                                                                                             \
+    step(std::integral_constant<int, 0>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 1>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 2>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 3>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 4>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 5>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 6>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 7>{}, std::integral_constant<int, PAR>{});                                    \
+    step(std::integral_constant<int, 8>{}, std::integral_constant<int, PAR>{});                                    \
+  } while (0)
+    for (; sl_c + 1 < nsl; sl_c += 2) {
+      PP_SLICE(0);
+      sl_c++;
+      PP_SLICE(1);
+      sl_c--;
+    }
+    if (sl_c < nsl) PP_SLICE(0);
+#undef PP_SLICE
+  } else {
   int tap_c = 0, sl_c = 0;      // tap / slice being computed
   int p_j = 0;                  // patch copies of slice sl_c + 1 issued so far
-  int c_prev = NWL;             // copies issued in the previous memory phase
   for (int ks = 0; ks < nk; ks++) {
     int fill = slot - 1;
     fill = fill < 0 ? NS - 1 : fill;
@@ -285,38 +409,11 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
         const int row = wcI * WC + a * 16 + fr;
         wf[a] = sWs[row * 4 + (fg ^ ((row >> 1) & 3))];
       }
-      if constexpr (FOLD) {
-        const int code = sQ[128 + tap_c];
-        const int dhs = (code & 3) - 1, dws = ((code >> 2) & 3) - 1;
-        int qq[FP];
 #pragma unroll
-        for (int b = 0; b < FP; b++) {
-          int q = q0[b] + qo;
-          const bool rh = dhs > 0 ? f_rT[b] : (dhs < 0 ? f_rB[b] : false);          // wave-uniform
-          const bool ch = dws > 0 ? f_hasL[b] : (dws < 0 ? f_hasR[b] : false);      // wave-uniform
-          const int vrow = dhs > 0 ? vT0 : vB0;
-          if (rh) q = vrow + f_lx[b] + dws + 1;                                     // VT / VB cell of column v + dw
-          if (ch) {
-            const bool cl = dws > 0 ? f_cL[b] : f_cR[b];                            // this lane's pixel is the column
-            const int alt = rh ? vrow + PW + (dws > 0 ? 0 : 1) : (dws > 0 ? vL0 : vR0) + f_ly[b] + dhs + 1;
-            q = cl ? alt : q;
-          }
-          qq[b] = q;
-        }
-#pragma unroll
-        for (int b = 0; b < FP; b++) xf[b] = sPs[qq[b] * 4 + (fg ^ ((qq[b] >> 1) & 3))];
-      } else {
-#pragma unroll
-        for (int b = 0; b < FP; b++) {
-          const int q = q0[b] + qo;
-          xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
-        }
+      for (int b = 0; b < FP; b++) {
+        const int q = q0[b] + qo;
+        xf[b] = sPs[q * 4 + (fg ^ ((q >> 1) & 3))];
       }
-    }
-    if constexpr (FOLD) {
-      // virtual cells of the NEXT slice's patch: all of its copies were issued in steps 0 .. 3 of this slice and have
-      // landed, for every wave, once group 0 enters step 6
-      if (tap_c == 6 && grp == 0 && sl_c + 1 < nsl) build_virtual((sl_c + 1) & 1);
     }
     tap_c++;
     if (tap_c == ntaps) { tap_c = 0; sl_c++; p_j = 0; }
@@ -342,6 +439,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     slot = slot + 1 == NS ? 0 : slot + 1;
+  }
   }
   if (!grp) {
     __builtin_amdgcn_sched_barrier(0);
@@ -472,9 +570,11 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
   }
   if (dry) return 102;
   if (p.fold)
-    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, true>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, true, true>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+  else if (q.ntaps == 9 && nmine <= 5)
+    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, false, true>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
   else
-    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, false>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
+    hipLaunchKernelGGL((igemm_pipe_patch_kernel<BF16, false, false>), dim3(total), dim3(512), 0, s, p, PH, PW, dhmin, dwmin, shift);
   MT_LAUNCH_CHECK();
   __atomic_fetch_add(&g_pp_launches, 1, __ATOMIC_RELAXED);
   return 0;
