@@ -98,8 +98,11 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
     # 0.15-1.2, every decoder tensor shrinks alike -- per-tensor table under MT_STEP_DIAG=2) nor even the direction is
     # stable: the `nearest` fixture's decoder gradient came out at cos +0.79, +0.79 and -0.90 in three consecutive runs of
     # the same binary (the order of the fp32 atomics in the fused statistics epilogue decides which side of a ReLU a
-    # handful of activations land on).  So phase 4 only gets a gross norm window in bf16; the fp32 run of the same fixture
-    # pins the logic to 1e-6, and at real widths bf16 tracks fp32 (tests/test_fullsize_gpu.py).
+    # handful of activations land on; with fixed-order reductions two runs are bit-identical -- verified in round 3).
+    # So HERE (atomics on, against fp64) phase 4 only gets a gross norm window in bf16; its direction and scale are
+    # pinned against the fp32 GPU run in deterministic mode by
+    # test_bf16_phase4_gradient_tracks_fp32_run_in_deterministic_mode below, the fp32 run of the same fixture pins the
+    # logic to 1e-6, and at real widths bf16 tracks fp32 (tests/test_fullsize_gpu.py).
     dir_tol = [(0.9, (0.85, 1.15))] * 2 + [(0.8, (0.9, 1.25))] * 3 + [(-1.0, (0.1, 3.0))] * 2
     # --dis_sn at these widths: with spectrally normalised weights the adversarial term dominates the generator
     # gradient, and d(logit)/d(image) is piecewise constant in the LeakyReLU pattern of a 4-channel discriminator.
@@ -209,6 +212,68 @@ def test_training_step_matches_reference_in_deterministic_mode(name, tmp_path, h
         test_training_step_matches_reference(name, "fp32", tmp_path, hip_device)
     finally:
         ops.set_deterministic(False)
+
+
+# bf16 phase 4 (backward_decoder_random) against the fp32 GPU run of the SAME fixture, both with fixed-order reductions
+# (ADVICE r2).  Measured over the fixtures in deterministic mode (tools/phase4_bf16_diag.py, round 3):
+# two bf16 runs are bit-identical (no race, no uninitialised read: the run-to-run flips seen in round 2 were the order of
+# the float atomics of the fused statistics epilogue), and against the fp32 run the phase-4 gradient of the width-8
+# fixtures keeps its direction and scale -- content encoder cos 0.70-0.91 / norm ratio 0.90-1.14, decoder cos 0.85-1.00 /
+# ratio 0.79-1.03.  The three width-4 fixtures (`--dim 4`: nearest, norms, wgangp) are the exception: their 4-channel
+# stacks put the phase-4 gradient at the mercy of single LeakyReLU / L1 sign patterns (tools/phase4_terms_diag.py: in
+# `nearest` the d l1_recon_z / d img_random field that comes back through the style encoder has cos -0.28 to the fp32
+# one while the forward image agrees to cos 0.9987, and the decoder's gradient is that field's near-cancelling pixel
+# sum), deterministic but not a statement about the code; their logic is pinned by the fp32 run of the same fixture.
+PHASE4_NARROW = {"adain_step_nearest", "adain_step_norms", "adain_step_wgangp"}
+PHASE4_FIXTURES = ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan", "adain_step_hinge",
+                   "adain_step_ragan", "adain_step_sn", "adain_step_dc", "base_step_concat", "adain_step_dropout",
+                   "base_step_concat_dropout", "adain_step_bn", "adain_step_ms"] + sorted(PHASE4_NARROW)
+
+
+def _phase4_gradients(name, tmp_path, precision):
+    z, meta, M, misc = _build(name, tmp_path, precision)
+    seen = []
+    for net, opt in M.optimizer.items():
+        orig = opt.step
+
+        def hooked(closure=None, _net=net, _orig=orig):
+            torch.cuda.synchronize()
+            seen.append((_net, torch.cat([p.grad.detach().double().flatten().cpu() for _, p in M.model[_net].named_parameters()
+                                          if p.grad is not None])))
+            return _orig()
+        opt.step = hooked
+    misc.set_random_source(misc.ReplaySource([z[f"rng/0/{i}"] for i in range(meta["rng_counts"][0])]))
+    try:
+        M.update_lr()
+        M.set_inputs(sub(z, "batch"))
+        M.optimize_parameters(0)
+    finally:
+        misc.set_random_source(None)
+    torch.cuda.synchronize()
+    return seen[-2:]            # the two optimizer steps of phase 4: content encoder, decoder
+
+
+@pytest.mark.parametrize("name", PHASE4_FIXTURES)
+def test_bf16_phase4_gradient_tracks_fp32_run_in_deterministic_mode(name, tmp_path, hip_device):
+    from masterthesis_amd import hip_ops as ops
+    ops.set_deterministic(True)
+    try:
+        ref = _phase4_gradients(name, tmp_path / "fp32", "fp32")
+        got = _phase4_gradients(name, tmp_path / "bf16", "bf16")
+    finally:
+        ops.set_deterministic(False)
+    assert [n for n, _ in ref] == [n for n, _ in got] == ["content_encoder", "decoder"]
+    for (net, a), (_, b) in zip(got, ref):
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
+        ratio = (a.norm() / (b.norm() + 1e-300)).item()
+        print(f"MT_DIAG phase4 {name} {net}: bf16 vs fp32 cos {cos:+.3f} ratio {ratio:.3f}")
+        assert torch.isfinite(a).all() and a.norm().item() > 0
+        if name in PHASE4_NARROW:
+            assert 0.2 <= ratio <= 2.0, f"{name} {net}: phase-4 gradient norm ratio {ratio:.3f} (width-4 fixture: gross bound only)"
+            continue
+        cos_min = 0.6 if net == "content_encoder" else 0.75
+        assert cos >= cos_min, f"{name} {net}: bf16 phase-4 gradient cosine {cos:.3f} to the fp32 run < {cos_min}"
+        assert 0.7 <= ratio <= 1.3, f"{name} {net}: bf16 phase-4 gradient norm ratio {ratio:.3f} to the fp32 run"
 
 
 def test_generator_outputs_within_1e3_of_reference(tmp_path, hip_device):
