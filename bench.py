@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the north-star metric: train images/sec of the full G+D step of AdaINModel at 256x256
-on synthetic batches (BASELINE.json configs[1]: 2 domains, batch 8, bf16, one MI355X), weak scaling
-over N GPUs (one process per GPU, RCCL gradient all-reduce).
+on synthetic batches, weak scaling over N GPUs (one process per GPU, RCCL gradient all-reduce).
+
+Headline workload (run with the multi-scale PatchGAN that north_star names, single-scale alongside):
+  N = 1   BASELINE.json configs[1]: 2 domains, 256x256, batch 8, bf16, --ms_dis
+  N > 1   BASELINE.json configs[3]: 4 domains, 256x256, batch 16 per GPU, bf16, --ms_dis  (the DDP shape)
+(`--single_scale`, `--batch_size`, `--num_domains` override; `extra` carries the single-scale step -- the headline of
+rounds 1-2 --, configs[2], the configs[4] per-GPU shape at 512x512, fp32, batch 1 and the hipGraph replays.)
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
@@ -148,14 +153,62 @@ def timed_run(o, rank, world, dev, steps, warmup, time_k1):
     return dt, k1_ms, losses
 
 
+# share of the reference step's algorithmic FLOPs that this implementation does not execute: the content- and style-encoder
+# forward of the discriminator update is shared with phase 3 (Ec fwd 178.88 + Es fwd 40.00 of 1203.47 / 1283.05
+# GMAC).  Every efficiency figure divides the FULL reference-equivalent F_step; the
+# executed figure is reported next to it.
+SHARED_ENCODER_GMAC = 178.88 + 40.00
+F_STEP_GMAC = {False: 1203.47, True: 1283.05}
+
+
 def step_numbers(o, dt, steps, world):
     ms_per_step = dt / steps * 1e3
     f_step = F_STEP_TFLOP[bool(o.ms_dis)] * o.batch_size * (o.crop_size ** 2 / 65536.0)
+    shared = os.environ.get("MT_NO_ENCODER_SHARING", "0") != "1"
+    f_exec = f_step * (1.0 - (SHARED_ENCODER_GMAC / F_STEP_GMAC[bool(o.ms_dis)] if shared else 0.0))
     peak = PEAK_BF16_TFLOPS if o.precision == "bf16" else PEAK_F32_TFLOPS
     return {"images_per_sec": round(2 * o.batch_size * world * steps / dt, 3), "ms_per_step": round(ms_per_step, 3),
             "step_tflop_algorithmic": round(f_step, 2),
+            "step_tflop_executed": round(f_exec, 2),
             "step_tflops_achieved_per_gpu": round(f_step / (ms_per_step * 1e-3), 1),
-            "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4)}
+            "step_tflops_executed_per_gpu": round(f_exec / (ms_per_step * 1e-3), 1),
+            "step_frac_of_mfma_peak": round(f_step / (ms_per_step * 1e-3) / peak, 4),
+            "step_frac_of_mfma_peak_executed": round(f_exec / (ms_per_step * 1e-3) / peak, 4)}
+
+
+def hbm_kernels(o, rank, world, dev):
+    """GB/s of the HBM-bound kernels inside the step (reported separately from the MFMA roofline): three more
+    steps of the headline configuration with HIP events around every launch of the normalisation statistics / apply
+    passes and of Adam; algorithmic bytes (operands read + written once) / launch time, against 8 TB/s."""
+    from masterthesis_amd import hip_ops as ops
+    import contextlib
+    from masterthesis_amd import models
+    from masterthesis_amd.dataset import SyntheticDataset
+    args = model_args(o, tempfile.mkdtemp())
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        M = models.AdaINModel(args)
+        M.initialize()
+    ds = SyntheticDataset(args, length=8, seed=1234 + rank)
+    items = [ds[i % 8] for i in range(o.batch_size)]
+    batch = {k: torch.stack([it[k] for it in items]).to(dev) for k in items[0]}
+    for it in range(5):
+        if it == 2:
+            torch.cuda.synchronize()
+            ops.hbm_timer_start()
+        M.update_lr()
+        M.set_inputs(batch)
+        M.optimize_parameters(it)
+    res = ops.hbm_timer_stop()
+    del M
+    torch.cuda.empty_cache()
+    out = {}
+    for name, (calls, ms, nbytes) in sorted(res.items()):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"calls_per_step": calls // 3, "ms_per_step": round(ms / 3, 3), "avg_us": round(ms / max(calls, 1) * 1e3, 1),
+                     "algorithmic_GB_per_step": round(nbytes / 3 / 1e9, 3), "achieved_GBps": round(gbs, 1),
+                     "frac_of_hbm_peak": round(gbs / 8000.0, 3)}
+    return out
 
 
 def workload_name(o):
@@ -169,12 +222,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch_size", type=int, default=8, help="pairs per GPU per step (BASELINE config 2: 8)")
+    ap.add_argument("--batch_size", type=int, default=0, help="pairs per GPU per step (default: 8 on one GPU = BASELINE "
+                    "configs[1], 16 per GPU on several = configs[3])")
     ap.add_argument("--crop_size", type=int, default=256)
-    ap.add_argument("--num_domains", type=int, default=2)
+    ap.add_argument("--num_domains", type=int, default=0, help="default: 2 on one GPU (configs[1]), 4 on several (configs[3])")
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--ms_dis", action="store_true", help="multi-scale discriminators for the headline run (default: "
-                    "single-scale, the reference's default; the --ms_dis step is always reported under 'extra')")
+    ap.add_argument("--ms_dis", action="store_true", help="(the default since round 3: multi-scale discriminators, the "
+                    "PatchGAN north_star names; kept for old command lines)")
+    ap.add_argument("--single_scale", action="store_true", help="single-scale discriminators (the reference's default and "
+                    "the headline of rounds 1-2) for the headline run; reported under 'extra' otherwise")
+    ap.add_argument("--no_hbm_kernels", action="store_true", help="skip the HBM-kernel GB/s block (three extra steps)")
     ap.add_argument("--cpu_res", type=int, default=0, help="resolution of the CPU-baseline steps (0 = the bench resolution)")
     ap.add_argument("--cpu_steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
     ap.add_argument("--cpu_budget_s", type=float, default=240.0)
@@ -193,6 +250,14 @@ def main():
     local = local % torch.cuda.device_count()       # (MT_DIST_BACKEND=gloo rehearsals: several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    o.ms_dis = not o.single_scale
+    if o.batch_size <= 0:
+        o.batch_size = 8 if world == 1 else 16
+    if o.num_domains <= 0:
+        o.num_domains = 2 if world == 1 else 4
+    if o.hip_graph and world > 1:
+        print("bench.py: --hip_graph with a live gradient exchange replays per-phase graphs (collectives stay outside)",
+              file=sys.stderr)
 
     if o.hip_graph:
         o.warmup = max(o.warmup, 6)
@@ -209,6 +274,9 @@ def main():
             variants.append(("single_scale", dict(ms_dis=False)))
         variants.append(("configs2_d4_b16_ms_dis", dict(num_domains=4, batch_size=16, ms_dis=True)))
         variants.append(("configs2_d4_b16_single_scale", dict(num_domains=4, batch_size=16, ms_dis=False)))
+        # the per-GPU shape of BASELINE configs[4]: 4 domains, 512x512, multi-scale discriminators (large-activation stress);
+        # batch 8 pairs = 16 images of 512x512 per step and GPU
+        variants.append(("configs4_d4_512_b8_ms_dis", dict(num_domains=4, batch_size=8, crop_size=512, ms_dis=True)))
         variants.append(("fp32" if o.precision == "bf16" else "bf16",
                          dict(precision="fp32" if o.precision == "bf16" else "bf16")))
         variants.append(("batch_size_1", dict(batch_size=1)))       # the reference's scripts/train.sh batch size
@@ -220,10 +288,15 @@ def main():
             for k, v in kw.items():
                 setattr(o2, k, v)
             k = max(3, min(o.steps, 10))
+            if getattr(o2, "crop_size", 256) > 256:
+                k = min(k, 5)
             w = 6 if getattr(o2, "hip_graph", False) else 3      # 3 eager iterations + the capturing one come first
             dt2, _, _ = timed_run(o2, rank, world, dev, k, w, time_k1=False)
             extra[name] = dict(workload=workload_name(o2) + (", hipGraph replay" if getattr(o2, "hip_graph", False) else ""),
                                steps=k, warmup=w, **step_numbers(o2, dt2, k, world))
+    hbm = None
+    if world == 1 and not o.no_hbm_kernels:
+        hbm = hbm_kernels(o, rank, world, dev)
     if rank != 0:
         return
     N_img = 2 * o.batch_size
@@ -241,14 +314,16 @@ def main():
     # HBM-side traffic of the dominant kernel per launch is NOT measured in this run: it is copied from the committed
     # rocprofv3 PMC passes of this exact shape (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md; collected
     # with tools/pmc_k1.sh) and labelled as such
-    traffic, mfma_busy, pmc_src = None, None, None
-    for cand in ("round2_k1_fwd_pmc.json", "round1_k1_fwd_pmc.json"):
+    traffic, mfma_busy, pmc_src, pmc_commit, pmc_kernel = None, None, None, None, None
+    for cand in ("round3_k1_fwd_pmc.json",):
+        # (only a PMC file collected on THIS round's kernel is cited: the round-2 file describes the ring kernel)
         pmc_path = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(pmc_path) and o.precision == "bf16" and o.batch_size == 8 and o.crop_size == 256:
             with open(pmc_path) as f:
                 pmc = json.load(f)
             traffic, mfma_busy = pmc.get("traffic_bytes_per_launch"), pmc.get("mfma_busy_fraction")
             pmc_src = "profiles/" + cand
+            pmc_commit, pmc_kernel = pmc.get("git_commit"), pmc.get("kernel")
             break
     out = {
         "metric": "train images/sec (G+D step), AdaINModel 256x256", "value": nums["images_per_sec"], "unit": "images/sec",
@@ -257,19 +332,27 @@ def main():
         "dtype": "bf16" if o.precision == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": workload_name(o),
                    "global_batch_pairs": o.batch_size * world, "parallelism": f"dp{world}",
+                   "baseline_config": "configs[1] + --ms_dis" if world == 1 else "configs[3]",
                    "step_tflop_algorithmic": nums["step_tflop_algorithmic"],
+                   "step_tflop_executed": nums["step_tflop_executed"],
                    "step_tflops_achieved_per_gpu": nums["step_tflops_achieved_per_gpu"],
-                   "step_frac_of_mfma_peak": nums["step_frac_of_mfma_peak"]},
-        "roofline": {"bound": "mfma", "kernel": ("igemm_pipe_kernel<bf16,256,256,512,4>" if o.precision == "bf16" else
-                                                 "igemm_pipe_kernel<f32,256,256,512,4>") + " fwd 3x3 s1 256->256 @64x64 "
-                                                "(+ fused InstanceNorm-statistics epilogue)",
+                   "step_tflops_executed_per_gpu": nums["step_tflops_executed_per_gpu"],
+                   "step_frac_of_mfma_peak": nums["step_frac_of_mfma_peak"],
+                   "step_frac_of_mfma_peak_executed": nums["step_frac_of_mfma_peak_executed"]},
+        "roofline": {"bound": "mfma", "kernel": ("igemm_pipe_patch_kernel<bf16,nofold,taps9>" if o.precision == "bf16" else
+                                                 "igemm_pipe_patch_kernel<f32,nofold,taps9>") + " fwd 3x3 s1 256->256 @64x64, "
+                                                "256x256 tiles, patch-resident pixel operand (+ fused InstanceNorm-statistics "
+                                                "epilogue)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": pmc_src,
+                     "traffic_git_commit": pmc_commit, "traffic_kernel": pmc_kernel,
                      "mfma_busy_fraction_pmc": mfma_busy,
                      "launches_timed": len(k1_ms), "avg_launch_ms_full_batch": round(k1_avg_ms, 4),
                      "flop_per_launch_full_batch": k1_flop},
         "final_losses": {k: round(float(v), 5) for k, v in losses.items()},
     }
+    if hbm:
+        out["hbm_kernels"] = hbm
     if extra:
         out["extra"] = extra
     if world == 1 and not o.no_cpu_baseline:

@@ -339,6 +339,48 @@ def oplog_stop():
     return out
 
 
+_HBMLOG = {"on": False, "events": []}
+
+
+def hbm_timer_start():
+    """Record HIP events around the HBM-bound kernels of the step (normalisation statistics / apply passes, Adam) together
+    with their algorithmic bytes (bench.py's ``hbm_kernels`` block; SURVEY 8d: GB/s of those kernels reported separately)."""
+    _HBMLOG["on"] = True
+    _HBMLOG["events"] = []
+
+
+def hbm_timer_stop():
+    """-> {kernel: (calls, total ms, total algorithmic bytes)} (synchronises)."""
+    _HBMLOG["on"] = False
+    torch.cuda.synchronize()
+    out = {}
+    for name, nbytes, a, b in _HBMLOG["events"]:
+        e = out.setdefault(name, [0, 0.0, 0])
+        e[0] += 1
+        e[1] += a.elapsed_time(b)
+        e[2] += nbytes
+    _HBMLOG["events"] = []
+    return {k: tuple(v) for k, v in out.items()}
+
+
+class _hbm:
+    """with _hbm(name, algorithmic bytes): <one launch>"""
+    def __init__(self, name, nbytes):
+        self.on = _HBMLOG["on"]
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _HBMLOG["events"].append((self.name, int(self.nbytes), self.e0, e1))
+
+
 class _oplog:
     def __init__(self, kind, desc, extra=()):
         self.on = _OPLOG["on"]
@@ -736,8 +778,9 @@ class _Norm(torch.autograd.Function):
         y = new_act(N, Cc, H, W, x.dtype, dev)
         if mode != L.NORM_BATCH and sums is not None and nparts == 1 and Cp <= 2048:
             # complete per-image statistics (the convolution's epilogue produced them): finalize + apply in ONE launch
-            L.check(lib.mt_norm_apply_fused(mt, mode, _ptr(x), _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(r), _ptr(y),
-                                            _ptr(coef), N, HW, Cc, Cp, act, slope, eps, _stream()), "mt_norm_apply_fused")
+            with _hbm("norm_apply_fused", N * HW * Cp * x.element_size() * (2 if r is None else 3)):
+                L.check(lib.mt_norm_apply_fused(mt, mode, _ptr(x), _ptr(sums), _ptr(gbc), _ptr(gm), _ptr(bt), _ptr(r), _ptr(y),
+                                                _ptr(coef), N, HW, Cc, Cp, act, slope, eps, _stream()), "mt_norm_apply_fused")
         else:
             if mode == L.NORM_BATCH:
                 rm, rv, momentum, training = bn
@@ -767,8 +810,9 @@ class _Norm(torch.autograd.Function):
         mt = _mt(x.dtype)
         nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
         sums2 = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)
-        L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
-                                    slope, _stream()), "mt_nc_stats_bwd")
+        with _hbm("nc_stats_bwd", N * HW * Cp * x.element_size() * 2):
+            L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
+                                        slope, _stream()), "mt_nc_stats_bwd")
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
         dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
         dgamma = dbeta = None
@@ -788,9 +832,10 @@ class _Norm(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cc, H, W, x.dtype, dev)
-            L.check(lib.mt_norm_bwd_apply(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(cc[0]),
-                                          _ptr(cc[1]), _ptr(cc[2]), _ptr(dx), N, HW, Cp, act, slope, _stream()),
-                    "mt_norm_bwd_apply")
+            with _hbm("norm_bwd_apply", N * HW * Cp * x.element_size() * 3):
+                L.check(lib.mt_norm_bwd_apply(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(cc[0]),
+                                              _ptr(cc[1]), _ptr(cc[2]), _ptr(dx), N, HW, Cp, act, slope, _stream()),
+                        "mt_norm_bwd_apply")
         gshape, bshape = ctx.shapes
         if dgamma is not None:
             dgamma = dgamma.view(gshape)

@@ -151,10 +151,12 @@ class FusedAdam(torch.optim.Adam):
         b1, b2 = g["betas"]
         # learning rate, step count and bias corrections live in the device record (ticked by the call itself): no
         # launch argument changes from step to step, so the update can be replayed from a captured hipGraph
-        L.check(L.load().mt_adam_multi_dev(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
-                                           self._flat[4], float(b1), float(b2), float(g["eps"]),
-                                           float(g["weight_decay"]), C.c_void_p(self._dev.data_ptr()), 1, ops._stream()),
-                "mt_adam_multi_dev")
+        # (4 reads -- parameter, gradient, both moments -- and 4 writes: the gradient is cleared in the same pass)
+        with ops._hbm("adam_multi", int(self._flat[4]) * 4 * 8):
+            L.check(L.load().mt_adam_multi_dev(C.c_void_p(self._ptrs.data_ptr()), C.c_void_p(self._sizes.data_ptr()), 1,
+                                               self._flat[4], float(b1), float(b2), float(g["eps"]),
+                                               float(g["weight_decay"]), C.c_void_p(self._dev.data_ptr()), 1, ops._stream()),
+                    "mt_adam_multi_dev")
         self._grads_clean = True
         ops.bump_epoch(self.params())
         ops.repack_params(self.params())    # all cached weight images of this network, one launch

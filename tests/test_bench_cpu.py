@@ -30,6 +30,10 @@ def test_step_numbers_follow_survey_8d():
     assert n["images_per_sec"] == 2 * 2 * 8 * 10 / 0.5                    # whole-job aggregate over the 8 ranks
     n = bench.step_numbers(_o(precision="fp32"), dt=2.0, steps=10, world=1)
     assert abs(n["step_frac_of_mfma_peak"] - 19.256 / 0.2 / 157.3) < 1e-3   # fp32 runs are priced against the fp32 peak
+    # the executed figure leaves out the encoder forward that the discriminator update shares with phase 3
+    n = bench.step_numbers(_o(), dt=0.4, steps=10, world=1)
+    assert abs(n["step_tflop_executed"] - 19.256 * (1 - (178.88 + 40.0) / 1203.47)) < 0.01
+    assert n["step_frac_of_mfma_peak_executed"] < n["step_frac_of_mfma_peak"]
 
 
 def test_workload_names_the_baseline_configuration():
