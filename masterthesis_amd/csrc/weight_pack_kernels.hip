@@ -73,15 +73,10 @@ __global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__
     const f32x4* q = reinterpret_cast<const f32x4*>(src + ((long)r * p.ntaps + t) * p.Cp) + c4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     int k = 0;
-    // up to 32 independent 16-byte loads in flight, added in index order.  (With four -- round 2 -- the 28 slabs of the K1
-    // weight gradient were seven dependent round trips per thread: 18.5 us for 66 MB = latency, not bandwidth.)
-    for (; k < nsplit; k += 32) {
-      f32x4 v[32];
-#pragma unroll
-      for (int j = 0; j < 32; j++)
-        v[j] = (k + j < nsplit) ? q[(long)(k + j) * (slab >> 2)] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 32; j++) a += v[j];
+    for (; k + 4 <= nsplit; k += 4) {             // four independent 16-byte loads in flight; added in index order
+      const f32x4 v0 = q[(long)k * (slab >> 2)], v1 = q[(long)(k + 1) * (slab >> 2)];
+      const f32x4 v2 = q[(long)(k + 2) * (slab >> 2)], v3 = q[(long)(k + 3) * (slab >> 2)];
+      a += v0; a += v1; a += v2; a += v3;
     }
     for (; k < nsplit; k++) a += q[(long)k * (slab >> 2)];
     float* d = dw + (long)r * p.sr + p.kh[t] * p.kW + p.kw[t];
