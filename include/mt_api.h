@@ -16,10 +16,11 @@
  *  - Ownership: the caller (PyTorch) allocates every buffer and workspace; the library
  *    borrows pointers for the duration of a call and never allocates or frees.
  *  - Every call takes the HIP stream explicitly; host side re-entrant, no host-side global state apart from the
- *    lazily loaded RCCL entry points of mt_comm_*.  One device-side exception: the scalar loss reductions (mt_bce_*_fwd,
- *    mt_gan_const_fwd, mt_l1_fwd, mt_l2mean_fwd, mt_kl_fwd) combine their block partials through a module-level scratch
- *    (fixed-order, reproducible sums without float atomics), so those calls must be stream-ordered with respect to each
- *    other -- issue them on one stream, as the step does.
+ *    lazily loaded RCCL entry points of mt_comm_* and one small table: the scalar loss reductions (mt_bce_*_fwd,
+ *    mt_gan_const_fwd, mt_l1_fwd, mt_l2mean_fwd, mt_kl_fwd) combine their block partials through a module-level device
+ *    scratch (fixed-order, reproducible sums without float atomics) that has ONE SLOT PER STREAM (up to 16 distinct
+ *    streams per process, assigned on first use): calls on one stream are ordered by the stream, calls on different
+ *    streams use different slots, so any stream may be passed.
  *  - Return value: 0 on success, non-zero on error; mt_last_error() gives a thread-local
  *    message.  No C++ exception crosses the ABI.
  */

@@ -159,33 +159,83 @@ extern "C" int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, vo
 
 // ---- batched pack: all weight images of a network in one launch ----------------------------------------------
 // mt_conv_pack_multi_build fills a HOST table (the caller copies it to the device once; weight and pack addresses
-// are stable across steps), mt_conv_pack_multi_run launches over the device copy.
-extern "C" size_t mt_conv_pack_multi_table_bytes(int n) { return (size_t)n * MT_MAX_PHASES * sizeof(PackEntry); }
+// are stable across steps), mt_conv_pack_multi_run launches over the device copy.  Table = [PackGroup x n] [PackEntry x ...]:
+// images of big k <= 4 weights go through the grouped LDS-tiled kernel (one read of the tensor for all of its images),
+// the rest (7x7 stem, thin 1x1 layers, small tensors) through the element-wise kernel.  The two counts returned to the
+// caller carry both kinds: n_entries = entries | groups << 16, total_blocks = entry blocks | n << 16.
+static size_t pack_groups_bytes(int n) { return (((size_t)n * sizeof(PackGroup)) + 255) & ~(size_t)255; }
+extern "C" size_t mt_conv_pack_multi_table_bytes(int n) {
+  return pack_groups_bytes(n) + (size_t)n * MT_MAX_PHASES * sizeof(PackEntry);
+}
 extern "C" int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const int* which, const float* const* w,
                                         void* const* packs, void* host_table, int* n_entries, int* total_blocks) {
-  PackEntry* tab = (PackEntry*)host_table;
-  int ne = 0, blocks = 0;
+  PackGroup* grp = (PackGroup*)host_table;
+  PackEntry* tab = (PackEntry*)((char*)host_table + pack_groups_bytes(n));
+  int ne = 0, blocks = 0, ng = 0;
   for (int i = 0; i < n; i++) {
     const mt_conv_desc* d = &descs[i];
     if (check_desc(d)) return 1;
+    const int K2 = d->kh * d->kw;
+    const int D0 = d->transposed ? d->Ci : d->Co, D1 = d->transposed ? d->Co : d->Ci;
     const int rc = pack_images(d, which[i], [&](const PackParams& p, size_t off) {
       const long total = (long)p.Rp * p.ntaps * p.Cp;
       if (total == 0) return 0;
+      // grouped path: the image is one of the two orientations of the contiguous [D0][D1][K2] tensor
+      const bool r0 = p.sr == (long)D1 * K2 && p.sc == K2 && p.R == D0 && p.C == D1;
+      const bool r1 = p.sr == K2 && p.sc == (long)D1 * K2 && p.R == D1 && p.C == D0;
+      if ((r0 || r1) && K2 <= 16 && K2 >= 4 && p.kW == d->kw && (long)D0 * D1 >= 8192) {
+        int gi = -1;
+        for (int k = 0; k < ng; k++)
+          if (grp[k].w == w[i] && grp[k].D0 == D0 && grp[k].D1 == D1 && grp[k].K2 == K2 &&
+              grp[k].bf16 == (d->dtype == MT_BF16) && grp[k].nout < MT_PACK_GROUP_OUTS)
+            gi = k;
+        if (gi < 0) {
+          gi = ng++;
+          memset(&grp[gi], 0, sizeof(PackGroup));
+          grp[gi].w = w[i]; grp[gi].D0 = D0; grp[gi].D1 = D1; grp[gi].K2 = K2; grp[gi].bf16 = d->dtype == MT_BF16;
+        }
+        PackOut& o = grp[gi].o[grp[gi].nout++];
+        o.out = (char*)packs[i] + off; o.rows_d0 = r0 ? 1 : 0; o.Rp = p.Rp; o.Cp = p.Cp; o.ntaps = p.ntaps;
+        for (int t = 0; t < p.ntaps; t++) o.tsrc[t] = (unsigned char)(p.kh[t] * p.kW + p.kw[t]);
+        return 0;
+      }
       PackEntry& e = tab[ne++];
       e.p = p; e.w = w[i]; e.out = (char*)packs[i] + off; e.bf16 = d->dtype == MT_BF16;
       e.blk0 = blocks;
-      e.nblk = (int)(total + 255) / 256 < 2048 ? (int)((total + 255) / 256) : 2048;
+      e.nblk = (int)(total + 255) / 256 < 512 ? (int)((total + 255) / 256) : 512;
       blocks += e.nblk;
       return 0;
     });
     if (rc) return rc;
   }
-  *n_entries = ne;
-  *total_blocks = blocks;
+  int tiles = 0;
+  for (int k = 0; k < ng; k++) {
+    // (tiles cover the padded extents of every image: rows / columns past the logical size are written as zeros)
+    int e0 = grp[k].D0, e1 = grp[k].D1;
+    for (int j = 0; j < grp[k].nout; j++) {
+      const PackOut& o = grp[k].o[j];
+      e0 = (o.rows_d0 ? o.Rp : o.Cp) > e0 ? (o.rows_d0 ? o.Rp : o.Cp) : e0;
+      e1 = (o.rows_d0 ? o.Cp : o.Rp) > e1 ? (o.rows_d0 ? o.Cp : o.Rp) : e1;
+    }
+    grp[k].tiles_d1 = (e1 + 31) / 32;
+    grp[k].ntiles = ((e0 + 31) / 32) * grp[k].tiles_d1;
+    grp[k].tile0 = tiles;
+    tiles += grp[k].ntiles;
+  }
+  MT_CHECK(ne < 65536 && ng < 32768 && blocks < 65536 && n < 65536, "pack_multi: table too large");
+  // (the element-wise blocks are capped at 512 per entry so that their sum fits 16 bits for any realistic network)
+  *n_entries = ne | (ng << 16);
+  *total_blocks = blocks | (n << 16);       // n locates the entries behind the groups' slots in the table
   return 0;
 }
 extern "C" int mt_conv_pack_multi_run(const void* dev_table, int n_entries, int total_blocks, mt_stream_t st) {
-  return mt_launch_pack_multi((const PackEntry*)dev_table, n_entries, total_blocks, (hipStream_t)st);
+  const int ne = n_entries & 0xffff, ng = (n_entries >> 16) & 0x7fff;
+  const int blocks = total_blocks & 0xffff, n = (total_blocks >> 16) & 0xffff;
+  const PackGroup* grp = (const PackGroup*)dev_table;
+  const PackEntry* tab = (const PackEntry*)((const char*)dev_table + pack_groups_bytes(n));
+  // (the group kernel reads its tile count from the table on the device; 2048 blocks walk the tiles)
+  if (mt_launch_pack_groups(grp, ng, 2048, (hipStream_t)st)) return 2;
+  return mt_launch_pack_multi(tab, ne, blocks, (hipStream_t)st);
 }
 
 // scatter-form launches shared by Conv2d bwd_data and ConvTranspose2d fwd.

@@ -112,6 +112,22 @@ struct PackEntry {
   int blk0, nblk;   // blocks [blk0, blk0 + nblk) of the launch belong to this entry
 };
 int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s);
+// grouped variant (weight_pack_kernels.hip): ONE coalesced read of a weight tensor [D0][D1][kh][kw] per 32 x 32 tile of
+// (d0, d1), all of the tensor's pack images written from the LDS copy in 64-byte runs
+#define MT_PACK_GROUP_OUTS 6
+struct PackOut {
+  void* out;
+  int rows_d0;      // image rows are d0 (else d1)
+  int Rp, Cp, ntaps;
+  unsigned char tsrc[MT_MAX_TAPS];   // source tap (kh * kW + kw) of image tap t
+};
+struct PackGroup {
+  const float* w;
+  int D0, D1, K2, bf16, nout;
+  int tile0, ntiles, tiles_d1;       // tiles [tile0, tile0 + ntiles) of the launch belong to this group
+  PackOut o[MT_PACK_GROUP_OUTS];
+};
+int mt_launch_pack_groups(const PackGroup* dev_groups, int ngroups, int blocks, hipStream_t s);
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,

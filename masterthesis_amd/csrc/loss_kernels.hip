@@ -9,12 +9,29 @@
 
 // Grid-wide sum of one value per thread into *dst, bit-reproducible: wave shuffle, the block's waves in index order,
 // the block partial into a scratch slot; the block that takes the last ticket adds the slots in a fixed order and
-// writes the scalar.  The scratch is a module-level device array: launches that use it must be stream ordered with
-// respect to each other (the library's loss kernels all run on the caller's one compute stream).  grid <= 1024 blocks
-// of 256 threads; EVERY thread of every block must call it exactly once.
-__device__ float g_red_part[1024];
-__device__ unsigned g_red_ticket = 0;
-__device__ __forceinline__ void grid_sum_to(float* dst, float v) {
+// writes the scalar.  The scratch is a module-level device array with one SLOT PER STREAM (red_slot: the C ABI accepts
+// any stream, and two reductions in flight on different streams must not share partials or the ticket):
+// launches on one stream are ordered, launches on different streams use different slots.  grid <= 1024 blocks of 256
+// threads; EVERY thread of every block must call it exactly once.
+#define RED_SLOTS 16
+__device__ float g_red_part[RED_SLOTS][1024];
+__device__ unsigned g_red_ticket[RED_SLOTS];
+#include <mutex>
+// slot of a stream (first come, first served; the table lives as long as the library: streams are few and long-lived)
+static int red_slot(hipStream_t s) {
+  static std::mutex mu;
+  static hipStream_t tab[RED_SLOTS];
+  static int n = 0;
+  std::lock_guard<std::mutex> g(mu);
+  for (int i = 0; i < n; i++)
+    if (tab[i] == s) return i;
+  if (n < RED_SLOTS) { tab[n] = s; return n++; }
+  return -1;
+}
+#define RED_SLOT_OR_FAIL(slot, s)                                                                     \
+  const int slot = red_slot(s);                                                                       \
+  MT_CHECK(slot >= 0, "loss reductions: more than %d distinct streams in one process", RED_SLOTS)
+__device__ __forceinline__ void grid_sum_to(float* dst, float v, int slot) {
   __shared__ float sw[4];
   __shared__ int last;
   v = wave_sum(v);
@@ -23,9 +40,9 @@ __device__ __forceinline__ void grid_sum_to(float* dst, float v) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const float b = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-    __hip_atomic_store(&g_red_part[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g_red_part[slot][blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
-    const unsigned t = atomicAdd(&g_red_ticket, 1u);
+    const unsigned t = atomicAdd(&g_red_ticket[slot], 1u);
     last = (t == gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
@@ -33,14 +50,14 @@ __device__ __forceinline__ void grid_sum_to(float* dst, float v) {
     __threadfence();
     float a = 0.f;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
-      a += __hip_atomic_load(&g_red_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a += __hip_atomic_load(&g_red_part[slot][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a = wave_sum(a);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sw[w] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
       *dst = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-      g_red_ticket = 0;
+      g_red_ticket[slot] = 0;
     }
   }
 }
@@ -58,7 +75,7 @@ static int zero_scalar(float* p, hipStream_t s) {
 // ---- BCE vs constant target on an NHWC-padded map -------------------------------------------
 template <bool BF16>
 __global__ void bce_const_fwd_kernel(const void* __restrict__ x, float t, float* __restrict__ loss, long npix,
-                                     int C, int Cp, float inv_count) {
+                                     int C, int Cp, float inv_count, int red_slot_id) {
   const long total = npix * C;
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -69,7 +86,7 @@ __global__ void bce_const_fwd_kernel(const void* __restrict__ x, float t, float*
     else v = reinterpret_cast<const float*>(x)[px * Cp + c];
     a += bce_logits(v, t);
   }
-  grid_sum_to(loss, a * inv_count);
+  grid_sum_to(loss, a * inv_count, red_slot_id);
 }
 template <bool BF16>
 __global__ void bce_const_bwd_kernel(const void* __restrict__ x, float t, const float* __restrict__ gscale,
@@ -92,12 +109,13 @@ __global__ void bce_const_bwd_kernel(const void* __restrict__ x, float t, const 
 extern "C" int mt_bce_const_fwd(int dtype, const void* x, float t, float* loss, size_t npix, int C, int Cp,
                                 mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
+  RED_SLOT_OR_FAIL(red_slot_id, s);
   if (zero_scalar(loss, s)) return 2;
   const long total = (long)npix * C;
   if (total == 0) return 0;
   const float inv = 1.f / (float)total;
-  if (dtype == MT_BF16) hipLaunchKernelGGL((bce_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv);
-  else hipLaunchKernelGGL((bce_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((bce_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv, red_slot_id);
+  else hipLaunchKernelGGL((bce_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, x, t, loss, (long)npix, C, Cp, inv, red_slot_id);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -133,7 +151,7 @@ __device__ __forceinline__ float gan_term_grad(int mode, float v, float t) {
 }
 template <bool BF16>
 __global__ void gan_const_fwd_kernel(int mode, const void* __restrict__ x, float t, float* __restrict__ loss, long npix,
-                                     int C, int Cp, float inv_count) {
+                                     int C, int Cp, float inv_count, int red_slot_id) {
   const long total = npix * C;
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -144,7 +162,7 @@ __global__ void gan_const_fwd_kernel(int mode, const void* __restrict__ x, float
     else v = reinterpret_cast<const float*>(x)[px * Cp + c];
     a += gan_term(mode, v, t);
   }
-  grid_sum_to(loss, a * inv_count);
+  grid_sum_to(loss, a * inv_count, red_slot_id);
 }
 template <bool BF16>
 __global__ void gan_const_bwd_kernel(int mode, const void* __restrict__ x, float t, const float* __restrict__ gscale,
@@ -168,12 +186,13 @@ extern "C" int mt_gan_const_fwd(int dtype, int mode, const void* x, float t, flo
                                 mt_stream_t st) {
   MT_CHECK(mode == MT_GAN_LSGAN || mode == MT_GAN_HINGE_D || mode == MT_GAN_NEG_MEAN, "gan_const: bad mode %d", mode);
   hipStream_t s = (hipStream_t)st;
+  RED_SLOT_OR_FAIL(red_slot_id, s);
   if (zero_scalar(loss, s)) return 2;
   const long total = (long)npix * C;
   if (total == 0) return 0;
   const float inv = 1.f / (float)total;
-  if (dtype == MT_BF16) hipLaunchKernelGGL((gan_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv);
-  else hipLaunchKernelGGL((gan_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((gan_const_fwd_kernel<true>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv, red_slot_id);
+  else hipLaunchKernelGGL((gan_const_fwd_kernel<false>), dim3(RED_GRID(total)), dim3(256), 0, s, mode, x, t, loss, (long)npix, C, Cp, inv, red_slot_id);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -192,11 +211,11 @@ extern "C" int mt_gan_const_bwd(int dtype, int mode, const void* x, float t, con
 
 // ---- BCE vs per-element target, fp32 vectors ---------------------------------------------------
 __global__ void bce_target_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                      float* __restrict__ loss, long n, float inv) {
+                                      float* __restrict__ loss, long n, float inv, int red_slot_id) {
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     a += bce_logits(x[i], t[i]);
-  grid_sum_to(loss, a * inv);
+  grid_sum_to(loss, a * inv, red_slot_id);
 }
 __global__ void bce_target_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                       const float* __restrict__ gscale, float* __restrict__ dx, long n,
@@ -207,9 +226,10 @@ __global__ void bce_target_bwd_kernel(const float* __restrict__ x, const float* 
 }
 extern "C" int mt_bce_target_fwd(const float* x, const float* t, float* loss, size_t n, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
+  RED_SLOT_OR_FAIL(red_slot_id, s);
   if (zero_scalar(loss, s)) return 2;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(bce_target_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, x, t, loss, (long)n, 1.f / (float)n);
+  hipLaunchKernelGGL(bce_target_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, x, t, loss, (long)n, 1.f / (float)n, red_slot_id);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -224,7 +244,7 @@ extern "C" int mt_bce_target_bwd(const float* x, const float* t, const float* gs
 // ---- L1 / mean-square over padded tensors (pad elements are zero in both operands) ---------
 template <bool BF16, int MODE>  // MODE 0: |a-b|, 1: a^2
 __global__ void absdiff_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
-                                   float* __restrict__ loss, long nchunks, float inv) {
+                                   float* __restrict__ loss, long nchunks, float inv, int red_slot_id) {
   constexpr int V = Elem<BF16>::V;
   float acc = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
@@ -239,7 +259,7 @@ __global__ void absdiff_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __r
       for (int e = 0; e < V; e++) acc += f[e] * f[e];
     }
   }
-  grid_sum_to(loss, acc * inv);
+  grid_sum_to(loss, acc * inv, red_slot_id);
 }
 template <bool BF16, int MODE>
 __global__ void absdiff_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
@@ -269,14 +289,15 @@ __global__ void absdiff_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __r
 }
 template <int MODE>
 static int absdiff_fwd(int dtype, const void* a, const void* b, float* loss, size_t n, size_t count, hipStream_t s) {
+  RED_SLOT_OR_FAIL(red_slot_id, s);
   if (zero_scalar(loss, s)) return 2;
   const int V = dtype == MT_BF16 ? 8 : 4;
   MT_CHECK(n % V == 0, "loss: element count %zu not a multiple of %d", n, V);
   const long nc = (long)(n / V);
   if (nc == 0 || count == 0) return 0;
   const float inv = 1.f / (float)count;
-  if (dtype == MT_BF16) hipLaunchKernelGGL((absdiff_fwd_kernel<true, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv);
-  else hipLaunchKernelGGL((absdiff_fwd_kernel<false, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((absdiff_fwd_kernel<true, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv, red_slot_id);
+  else hipLaunchKernelGGL((absdiff_fwd_kernel<false, MODE>), dim3(RED_GRID(nc)), dim3(256), 0, s, (const u32x4*)a, (const u32x4*)b, loss, nc, inv, red_slot_id);
   MT_LAUNCH_CHECK();
   return 0;
 }
@@ -337,11 +358,11 @@ extern "C" int mt_reparam_bwd(const float* logvar, const float* eps, const float
   return 0;
 }
 __global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
-                              float* __restrict__ kl, long n) {
+                              float* __restrict__ kl, long n, int red_slot_id) {
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     a += 1.f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
-  grid_sum_to(kl, -0.5f * a);
+  grid_sum_to(kl, -0.5f * a, red_slot_id);
 }
 __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                               const float* __restrict__ gscale, float* __restrict__ dmu,
@@ -354,9 +375,10 @@ __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restr
 }
 extern "C" int mt_kl_fwd(const float* mu, const float* logvar, float* kl, size_t n, mt_stream_t st) {
   hipStream_t s = (hipStream_t)st;
+  RED_SLOT_OR_FAIL(red_slot_id, s);
   if (zero_scalar(kl, s)) return 2;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, mu, logvar, kl, (long)n);
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(RED_GRID(n)), dim3(256), 0, s, mu, logvar, kl, (long)n, red_slot_id);
   MT_LAUNCH_CHECK();
   return 0;
 }

@@ -72,6 +72,7 @@ class _ZeroArena:
         self.off = self.dirty = self.need = self.asked = self.depth = 0
         self.high = 0       # high-water mark of handed-out floats: the memset always covers it, so a step captured into a
                             # hipGraph re-zeroes everything ANY kind of step may have dirtied before it
+        self.generation = 0  # bumped whenever the buffer is reallocated: a captured graph holds the OLD address
 
     def begin(self, device):
         self.depth += 1
@@ -81,6 +82,7 @@ class _ZeroArena:
         if self.buf is None or self.buf.device != device or self.buf.numel() < want:
             self.buf = torch.zeros(int(want * 1.25), dtype=torch.float32, device=device)
             self.high = 0
+            self.generation += 1
         elif self.dirty:
             self.buf[:self.dirty].zero_()
         self.off = self.dirty = self.asked = 0
@@ -234,6 +236,13 @@ def _get_pack(owner, weight, desc, which):
 
 
 _PACK_TABLES = {}
+_PACK_TABLES_GEN = [0]      # bumped when the tables are dropped: a captured mt_conv_pack_multi_run reads the OLD table
+
+
+def graph_epoch():
+    """Changes whenever a device buffer that captured step graphs have baked in by ADDRESS was freed or reallocated (the
+    zero arena, the batched-pack tables): part of the graph key, so a stale graph is never replayed."""
+    return (_arena.generation, _PACK_TABLES_GEN[0])
 
 
 def repack_params(params):
@@ -264,6 +273,7 @@ def repack_params(params):
         dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(items[0][0].device)
         if len(_PACK_TABLES) > 64:
             _PACK_TABLES.clear()
+            _PACK_TABLES_GEN[0] += 1
         tab = (dev, ne.value, nb.value)
         _PACK_TABLES[sig] = tab
     L.check(lib.mt_conv_pack_multi_run(_ptr(tab[0]), tab[1], tab[2], _stream()), "mt_conv_pack_multi_run")

@@ -118,8 +118,10 @@ class TranslationModel(Model):
         # (anything that changes the launch sequence invalidates the capture: rebuilt flat buffers, train / eval flags,
         #  deterministic mode, the storage type)
         key = (kind, tuple(o.generation for o in opts), ops.compute_dtype(), ops.deterministic(),
-               tuple(self.model[n].training for n in self.model))
+               tuple(self.model[n].training for n in self.model), ops.graph_epoch())
         graphs = self.__dict__.setdefault("_graphs", {})
+        for k in [k for k in graphs if k[0] == kind and k != key and (k[1] != key[1] or k[5] != key[5])]:
+            del graphs[k]       # captured against flat buffers / arena / pack tables that no longer exist: never replayable
         st = graphs.setdefault(key, {"warm": 0})
         if st["warm"] < self.GRAPH_WARMUP:           # eager steps first: caches, flat buffers, pack tables, arenas settle
             st["warm"] += 1
@@ -219,9 +221,13 @@ class TranslationModel(Model):
         if not (on and not torch.is_grad_enabled() and torch.cuda.is_available()
                 and isinstance(random_source(), DeviceRandom)):
             return fn(*inputs)
+        # (the weights' versions: a checkpoint load or an optimizer step re-packs the weight images outside the graph)
+        wver = tuple(sum(p._version for p in self.model[n].parameters()) for n in self.model)
         key = (name, ops.compute_dtype(), tuple((tuple(t.shape), t.dtype) for t in inputs),
-               tuple(self.model[n].training for n in self.model))
+               tuple(self.model[n].training for n in self.model), ops.graph_epoch(), wver)
         graphs = self.__dict__.setdefault("_infer_graphs", {})
+        for k in [k for k in graphs if k[0] == name and k != key and k[4:] != key[4:]]:
+            del graphs[k]       # captured against other weights / freed scratch: never replayable
         st = graphs.setdefault(key, {"warm": 0})
         if st["warm"] < 2:
             st["warm"] += 1
