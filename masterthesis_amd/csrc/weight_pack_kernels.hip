@@ -78,16 +78,30 @@ __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, fl
     const float inv_nt = 1.0f / (float)nt;
     const int rows_d0 = o.rows_d0, Rp = o.Rp, Cp = o.Cp;
     const int r0 = rows_d0 ? d00 : d10, c0 = rows_d0 ? d10 : d00;
-    for (int idx = threadIdx.x; idx < 32 * nt * 32; idx += 256) {
-      const int cl = idx & 31, q = idx >> 5;
+    // one thread = 8 consecutive columns of one (row, tap): a 16-byte store (2-byte stores are ~12x slower per byte,
+    // MI355X_MICROARCH.md: that, not the read amplification, bounded the element-wise kernels too)
+    for (int idx = threadIdx.x; idx < 32 * nt * 4; idx += 256) {
+      const int c8 = idx & 3, q = idx >> 2;
       const int rl = (int)(((float)q + 0.5f) * inv_nt), t = q - rl * nt;
-      const int d0l = rows_d0 ? rl : cl, d1l = rows_d0 ? cl : rl;
-      const int r = r0 + rl, c = c0 + cl;
-      if (r < Rp && c < Cp) {
-        const float v = sm[(d0l * 32 + d1l) * K2p + s_t[t]];
+      const int r = r0 + rl, c = c0 + c8 * 8;
+      if (r < Rp && c < Cp) {            // (Cp is a multiple of 8: a chunk is inside or outside as a whole)
+        const int ts = s_t[t];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int cl = c8 * 8 + e;
+          const int d0l = rows_d0 ? rl : cl, d1l = rows_d0 ? cl : rl;
+          v[e] = sm[(d0l * 32 + d1l) * K2p + ts];
+        }
         const long di = ((long)r * nt + t) * Cp + c;
-        if constexpr (BF16) reinterpret_cast<unsigned short*>(o.out)[di] = f32_to_bf16_bits(v);
-        else reinterpret_cast<float*>(o.out)[di] = v;
+        if constexpr (BF16) {
+          const u32x4 pk = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(o.out) + di) = pk;
+        } else {
+          float* dst = reinterpret_cast<float*>(o.out) + di;
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
       }
     }
     __syncthreads();
