@@ -183,7 +183,7 @@ extern "C" int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const 
       // grouped path: the image is one of the two orientations of the contiguous [D0][D1][K2] tensor
       const bool r0 = p.sr == (long)D1 * K2 && p.sc == K2 && p.R == D0 && p.C == D1;
       const bool r1 = p.sr == K2 && p.sc == (long)D1 * K2 && p.R == D1 && p.C == D0;
-      if ((r0 || r1) && K2 <= 16 && K2 >= 4 && p.kW == d->kw && (long)D0 * D1 >= 8192) {
+      if ((r0 || r1) && d->dtype == MT_BF16 && K2 <= 16 && K2 >= 4 && p.kW == d->kw && (long)D0 * D1 >= 8192) {
         int gi = -1;
         for (int k = 0; k < ng; k++)
           if (grp[k].w == w[i] && grp[k].D0 == D0 && grp[k].D1 == D1 && grp[k].K2 == K2 &&

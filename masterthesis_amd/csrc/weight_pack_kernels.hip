@@ -3,6 +3,7 @@
 // (unpack: sums the pixel-split slabs, optionally accumulating into param.grad).
 #include "mt_common.h"
 #include "conv_params.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // weight (un)packing between the reference layouts and [row][tap][col] tiles
@@ -51,22 +52,45 @@ __global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
 // ALL K2 <= 16 taps -- 32 contiguous runs of 32 * K2 floats -- into LDS once, and writes every image of the tensor from
 // there: rows of 32 consecutive columns = 64-byte (bf16) runs, for either orientation.  The fp32 source is read once
 // per optimizer step instead of once per image with 9-16x sector amplification.
+// LDS image of a tile: per source tap k one 32 x 32 plane in the output element type, TWICE -- [k][d0][d1] for the images
+// whose rows are d0 and [k][d1][d0] for the transposed ones -- so that 8 consecutive output columns are ONE 16-byte LDS
+// read followed by ONE 16-byte store for either orientation.  Plane pitch 32 * 32 + 8 elements (conflict-free tap walks
+// when the tile is written: consecutive lanes hold consecutive taps of one (d0, d1)).
 template <bool BF16>
-__device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, float* sm, unsigned char* s_t) {
-  const int K2 = g.K2, K2p = K2 | 1;                 // odd pitch: conflict-free column walks
+__device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, char* smraw, unsigned char* s_t) {
+  typedef typename std::conditional<BF16, unsigned short, float>::type T;
+  constexpr int PL = 32 * 32 + 8;                    // elements per plane
+  constexpr int EV = BF16 ? 8 : 4;                   // elements per 16 bytes
+  T* const sA = reinterpret_cast<T*>(smraw);         // [k][d0l][d1l]
+  const int K2 = g.K2;
+  T* const sB = sA + K2 * PL;                        // [k][d1l][d0l]
   const int td0 = tile / g.tiles_d1, td1 = tile - td0 * g.tiles_d1;
   const int d00 = td0 * 32, d10 = td1 * 32;
   const int run = 32 * K2;                            // floats of one d0 row of the tile (contiguous in the source)
   const float inv_k2 = 1.0f / (float)K2;
   // (small-integer divisions by multiplication: (j + 0.5) / K2 is at least 0.5 / K2 away from an integer)
+  const bool vec = (((long)g.D1 * K2) & 3) == 0 && d10 + 32 <= g.D1;      // 16-byte source loads
   for (int d0l = 0; d0l < 32; d0l++) {
     const int d0 = d00 + d0l;
     const float* src = g.w + ((long)d0 * g.D1 + d10) * K2;
-    for (int j = threadIdx.x; j < run; j += 256) {
+    auto put = [&](int j, float v) {
       const int d1l = (int)(((float)j + 0.5f) * inv_k2), k = j - d1l * K2;
-      float v = 0.f;
-      if (d0 < g.D0 && d10 + d1l < g.D1) v = src[j];
-      sm[(d0l * 32 + d1l) * K2p + k] = v;
+      T e;
+      if constexpr (BF16) e = f32_to_bf16_bits(v); else e = v;
+      sA[k * PL + d0l * 32 + d1l] = e;
+      sB[k * PL + d1l * 32 + d0l] = e;
+    };
+    if (vec && d0 < g.D0) {
+      for (int j4 = threadIdx.x; j4 < run / 4; j4 += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[j4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) put(j4 * 4 + e, v[e]);
+      }
+    } else {
+      for (int j = threadIdx.x; j < run; j += 256) {
+        const int d1l = (int)(((float)j + 0.5f) * inv_k2);
+        put(j, (d0 < g.D0 && d10 + d1l < g.D1) ? src[j] : 0.f);
+      }
     }
   }
   __syncthreads();
@@ -78,37 +102,25 @@ __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, fl
     const float inv_nt = 1.0f / (float)nt;
     const int rows_d0 = o.rows_d0, Rp = o.Rp, Cp = o.Cp;
     const int r0 = rows_d0 ? d00 : d10, c0 = rows_d0 ? d10 : d00;
-    // one thread = 8 consecutive columns of one (row, tap): a 16-byte store (2-byte stores are ~12x slower per byte,
-    // MI355X_MICROARCH.md: that, not the read amplification, bounded the element-wise kernels too)
-    for (int idx = threadIdx.x; idx < 32 * nt * 4; idx += 256) {
-      const int c8 = idx & 3, q = idx >> 2;
+    const T* const sS = rows_d0 ? sA : sB;
+    // one thread = 16 bytes of consecutive columns of one (row, tap): a 16-byte store (2-byte stores are ~12x slower per
+    // byte, MI355X_MICROARCH.md: that, not the read amplification, bounded the element-wise kernels too)
+    constexpr int NCH = 32 / EV;
+    for (int idx = threadIdx.x; idx < 32 * nt * NCH; idx += 256) {
+      const int ch = idx % NCH, q = idx / NCH;
       const int rl = (int)(((float)q + 0.5f) * inv_nt), t = q - rl * nt;
-      const int r = r0 + rl, c = c0 + c8 * 8;
+      const int r = r0 + rl, c = c0 + ch * EV;
       if (r < Rp && c < Cp) {            // (Cp is a multiple of 8: a chunk is inside or outside as a whole)
-        const int ts = s_t[t];
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int cl = c8 * 8 + e;
-          const int d0l = rows_d0 ? rl : cl, d1l = rows_d0 ? cl : rl;
-          v[e] = sm[(d0l * 32 + d1l) * K2p + ts];
-        }
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sS + (int)s_t[t] * PL + rl * 32 + ch * EV);
         const long di = ((long)r * nt + t) * Cp + c;
-        if constexpr (BF16) {
-          const u32x4 pk = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
-          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(o.out) + di) = pk;
-        } else {
-          float* dst = reinterpret_cast<float*>(o.out) + di;
-          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(o.out) + di) = v;
       }
     }
     __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void pack_group_kernel(const PackGroup* __restrict__ groups, int ng) {
-  __shared__ float sm[32 * 32 * 17];
+  __shared__ __attribute__((aligned(16))) char sm[2 * 16 * (32 * 32 + 8) * 2];       // two copies, 16 taps, bf16 elements (fp32 images take the element-wise kernel)
   __shared__ unsigned char s_t[MT_MAX_TAPS];
   const int total_tiles = groups[ng - 1].tile0 + groups[ng - 1].ntiles;
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
@@ -118,8 +130,7 @@ __global__ __launch_bounds__(256) void pack_group_kernel(const PackGroup* __rest
       if (tile >= groups[mid].tile0) lo = mid; else hi = mid - 1;
     }
     const PackGroup& g = groups[lo];
-    if (g.bf16) pack_group_tile<true>(g, tile - g.tile0, sm, s_t);
-    else pack_group_tile<false>(g, tile - g.tile0, sm, s_t);
+    pack_group_tile<true>(g, tile - g.tile0, sm, s_t);
   }
 }
 int mt_launch_pack_groups(const PackGroup* dev_groups, int ngroups, int blocks, hipStream_t s) {
