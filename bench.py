@@ -154,10 +154,11 @@ def timed_run(o, rank, world, dev, steps, warmup, time_k1):
 
 
 # share of the reference step's algorithmic FLOPs that this implementation does not execute: the content- and style-encoder
-# forward of the discriminator update is shared with phase 3 (Ec fwd 178.88 + Es fwd 40.00 of 1203.47 / 1283.05
-# GMAC).  Every efficiency figure divides the FULL reference-equivalent F_step; the
-# executed figure is reported next to it.
-SHARED_ENCODER_GMAC = 178.88 + 40.00
+# forward of the discriminator update is shared with phase 3: ONE of the four content-encoder and ONE of the four
+# style-encoder forward calls of a step (Ec fwd 178.88, Es fwd 40.00 GMAC over four calls each, of
+# 1203.47 / 1283.05 GMAC) = 4.5 % / 4.3 %.  Every efficiency figure divides the FULL reference-equivalent F_step;
+# the executed figure is reported next to it.
+SHARED_ENCODER_GMAC = (178.88 + 40.00) / 4.0
 F_STEP_GMAC = {False: 1203.47, True: 1283.05}
 
 

@@ -86,7 +86,9 @@ int mt_conv_pack(const mt_conv_desc* d, int which, const float* w, void* pack, m
 /* Batched pack of n (descriptor, which, weights, pack buffer) tuples in ONE launch (a network's weights after its
  * optimizer step).  _build fills a HOST table of mt_conv_pack_multi_table_bytes(n) bytes; the caller copies it to
  * device memory once (the addresses in it must stay valid) and calls _run with that copy whenever the weights
- * changed.  Same images as mt_conv_pack. */
+ * changed.  Same images as mt_conv_pack, byte for byte.  *n_entries / *total_blocks are opaque values to hand back to
+ * _run (they carry the counts of both kernels behind the call: tensors with k*k <= 16 taps are read ONCE per call through
+ * LDS tiles for all of their images, the rest element-wise).  _run issues at most two launches on `s`. */
 size_t mt_conv_pack_multi_table_bytes(int n);
 int mt_conv_pack_multi_build(int n, const mt_conv_desc* descs, const int* which, const float* const* w,
                              void* const* packs, void* host_table, int* n_entries, int* total_blocks);

@@ -32,7 +32,7 @@ def test_step_numbers_follow_survey_8d():
     assert abs(n["step_frac_of_mfma_peak"] - 19.256 / 0.2 / 157.3) < 1e-3   # fp32 runs are priced against the fp32 peak
     # the executed figure leaves out the encoder forward that the discriminator update shares with phase 3
     n = bench.step_numbers(_o(), dt=0.4, steps=10, world=1)
-    assert abs(n["step_tflop_executed"] - 19.256 * (1 - (178.88 + 40.0) / 1203.47)) < 0.01
+    assert abs(n["step_tflop_executed"] - 19.256 * (1 - (178.88 + 40.0) / 4 / 1203.47)) < 0.01
     assert n["step_frac_of_mfma_peak_executed"] < n["step_frac_of_mfma_peak"]
 
 
