@@ -1171,35 +1171,6 @@ def cat_batch(ts):
     return _CatBatch.apply(*ts)
 
 
-class _EmbedBatch(torch.autograd.Function):
-    """Batch of zero canvases [sum N_i, C, H, W] with t_i copied into the top-left corner of its images."""
-    @staticmethod
-    def forward(ctx, H, W, *ts):
-        t0 = ts[0]
-        Cc = t0.shape[1]
-        out = new_act(sum(t.shape[0] for t in ts), Cc, H, W, compute_dtype(), t0.device, zero=True)
-        n0, spans = 0, []
-        for t in ts:
-            n, _, h, w = t.shape
-            out[n0:n0 + n, :, :h, :w].copy_(t)
-            spans.append((n0, n, h, w))
-            n0 += n
-        ctx.spans = spans
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        return (None, None) + tuple(canon(dy[n0:n0 + n, :, :h, :w]) for n0, n, h, w in ctx.spans)
-
-
-def embed_batch(ts, H, W):
-    """One batch of H x W zero canvases holding the (smaller or equal) maps ``ts`` top-left aligned.  A zero-padded
-    convolution on the canvas gives, at the positions of the original output map, exactly the original outputs (the
-    zeros to the right of / below a map are the convolution's own zero padding), so weight-shared stacks applied to
-    several scales can run as ONE batch where launch and weight-streaming cost outweigh the wasted canvas FLOPs."""
-    return _EmbedBatch.apply(int(H), int(W), *[canon(t) for t in ts])
-
-
 # --------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------

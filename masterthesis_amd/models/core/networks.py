@@ -8,8 +8,6 @@ padded-NHWC activation (see ``hip_ops``).  ``ResnetGenerator`` (468-512) is unus
 models and not provided.
 """
 import numpy as np
-import os
-
 import torch
 import torch.nn as nn
 
@@ -285,62 +283,14 @@ class MultiScaleDiscriminator(nn.Module):
         self.cls = nn.Conv2d(dim, num_domains, 1, 1, 0)
         self.pool = _Marker("adaptive_avgpool")
 
-    def _batched_from(self, xs):
-        """Index of the first layer that runs ONCE on a batch of zero canvases holding all scales (ops.embed_batch), or
-        None.  The three scales share weights (networks.py:445-466) and the deep layers are launch- and weight-streaming
-        bound at every scale (1024 -> 2048 channels on 8x8 / 4x4 / 2x2 maps: 67 MB of weights and a 134 MB weight-gradient
-        slab per call for 0.5-8 MFLOP per image), so from that layer on one launch serves the three of them; outputs at
-        the positions of each scale's own map are exactly those of the separate calls.  Only for plain zero-padded
-        convolution + activation layers (no norm layer: its statistics would see the canvas; no spectral norm: its power
-        iteration runs per call in the reference) and only when every scale is large enough to run at all."""
-        k0 = int(os.environ.get("MT_MSD_BATCH_FROM", str(len(self.model) - 1)))
-        if self.num_scales < 2 or k0 < 1 or k0 >= len(self.model):
-            return None
-        for layer in self.model[k0:]:
-            conv = layer.block[layer._ci]
-            if layer.norm is not None or layer.pad_mode != "zero" or not isinstance(conv, nn.Conv2d) or hasattr(conv, "weight_orig"):
-                return None
-        for x in xs:                         # (a scale too small for the stack: let the plain path raise like the reference)
-            h, w = x.shape[2], x.shape[3]
-            for layer in self.model:
-                k = layer.block[layer._ci].kernel_size[0]
-                h, w = (h + 2 * layer.padding - k) // layer.stride + 1, (w + 2 * layer.padding - k) // layer.stride + 1
-                if h < 1 or w < 1:
-                    return None
-        return k0
-
     def forward(self, x):
-        xs = [x]
-        for _ in range(self.num_scales - 1):
-            xs.append(ops.avg_pool3s2(xs[-1]))
-        k0 = self._batched_from(xs)
-        heads = []
-        if k0 is None:
-            for xi in xs:
-                h = xi
-                for layer in self.model:
-                    h = layer(h)
-                heads.append(h)
-        else:
-            hs = []
-            for xi in xs:
-                h = xi
-                for layer in self.model[:k0]:
-                    h = layer(h)
-                hs.append(h)
-            N = hs[0].shape[0]
-            hb = ops.embed_batch(hs, hs[0].shape[2], hs[0].shape[3])
-            for layer in self.model[k0:]:
-                hb = layer(hb)
-            for s, h in enumerate(hs):
-                hh, ww = h.shape[2], h.shape[3]
-                for layer in self.model[k0:]:
-                    k = layer.block[layer._ci].kernel_size[0]
-                    hh, ww = (hh + 2 * layer.padding - k) // layer.stride + 1, (ww + 2 * layer.padding - k) // layer.stride + 1
-                heads.append(hb[s * N:(s + 1) * N, :, :hh, :ww])
         outputs = []
-        for h in heads:
+        for _ in range(self.num_scales):
+            h = x
+            for layer in self.model:
+                h = layer(h)
             dis = ops.conv2d(h, self.dis.weight, self.dis.bias)
             c = ops.global_avg_pool(ops.conv2d(h, self.cls.weight, self.cls.bias))
             outputs.append((dis, c))
+            x = ops.avg_pool3s2(x)
         return outputs

@@ -416,42 +416,3 @@ def test_every_network_backward_matches_oracle(tag, hip_device):
             got = (ops.to_nchw_f32(got) if got.dim() == 4 else got.float()).cpu().double()
             rel = ((got - in64[k].grad).norm() / in64[k].grad.norm()).item()
             assert rel < 2e-3, f"{tag}: input gradient d{k} rel L2 {rel:.2e}"
-
-
-@pytest.mark.parametrize("k0", [5, 3])
-def test_multi_scale_discriminator_scale_batching_is_transparent(k0, hip_device, monkeypatch):
-    """The deep layers of the weight-shared multi-scale discriminator run ONCE on a batch of zero canvases holding all
-    three scales (networks.MultiScaleDiscriminator._batched_from): outputs and every gradient must be those of the
-    separate per-scale calls (fp32: up to summation order; the zeros beside a map are the convolution's own padding)."""
-    from masterthesis_amd import hip_ops as ops
-    from masterthesis_amd.models.core import networks as N
-    from masterthesis_amd.models.core.functions import init_weights
-    ops.set_compute_dtype(torch.float32)
-    try:
-        torch.manual_seed(3)
-        net = N.MultiScaleDiscriminator(3, dim=8, num_domains=4)
-        init_weights(net, "normal", 0.2)
-        net = net.to(hip_device)
-        x0 = torch.randn(3, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(hip_device)
-        res = {}
-        for tag, env in (("separate", "0"), ("batched", str(k0))):
-            monkeypatch.setenv("MT_MSD_BATCH_FROM", env)
-            for p in net.parameters():
-                p.grad = None
-            x = x0.clone().requires_grad_()
-            outs = net(x)
-            assert (net._batched_from([x, x[:, :, ::2, ::2], x[:, :, ::4, ::4]]) is None) == (env == "0")
-            flat = [t for pair in outs for t in pair]
-            g = torch.Generator().manual_seed(7)
-            cot = [torch.randn(t.shape, generator=g).to(hip_device) for t in flat]
-            torch.autograd.backward(flat, [ops.canon(c) if c.dim() == 4 else c for c in cot])
-            res[tag] = ([(ops.to_nchw_f32(t) if t.dim() == 4 else t.float()).detach().cpu() for t in flat],
-                        [p.grad.detach().cpu().clone() for p in net.parameters()], x.grad.detach().cpu().clone())
-        for a, b in zip(res["batched"][0], res["separate"][0]):
-            assert a.shape == b.shape
-            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6) + 1e-7
-        for a, b in zip(res["batched"][1], res["separate"][1]):
-            assert ((a - b).norm() / (b.norm() + 1e-30)).item() < 1e-4
-        assert ((res["batched"][2] - res["separate"][2]).norm() / res["separate"][2].norm()).item() < 1e-4
-    finally:
-        ops.set_compute_dtype(torch.bfloat16)
