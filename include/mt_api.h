@@ -18,9 +18,9 @@
  *  - Every call takes the HIP stream explicitly; host side re-entrant, no host-side global state apart from the
  *    lazily loaded RCCL entry points of mt_comm_* and one small table: the scalar loss reductions (mt_bce_*_fwd,
  *    mt_gan_const_fwd, mt_l1_fwd, mt_l2mean_fwd, mt_kl_fwd) combine their block partials through a module-level device
- *    scratch (fixed-order, reproducible sums without float atomics) that has ONE SLOT PER STREAM (up to 16 distinct
- *    streams per process, assigned on first use): calls on one stream are ordered by the stream, calls on different
- *    streams use different slots, so any stream may be passed.
+ *    scratch (fixed-order, reproducible sums without float atomics) that has ONE SLOT PER STREAM (the first 16 distinct
+ *    streams of a process get their own, assigned on first use; later ones share by address): calls on one stream are
+ *    ordered by the stream, calls on different streams use different slots, so any stream may be passed.
  *  - Return value: 0 on success, non-zero on error; mt_last_error() gives a thread-local
  *    message.  No C++ exception crosses the ABI.
  */

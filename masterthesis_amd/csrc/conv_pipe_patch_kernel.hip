@@ -34,6 +34,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef PP_PATCH_AUX
+#define PP_PATCH_AUX 0          // cache policy of the patch copies / weight copies (experiments: tools/diag_build.sh)
+#endif
+#ifndef PP_WEIGHT_AUX
+#define PP_WEIGHT_AUX 0
+#endif
 constexpr int MT_PP_PCAP = 560;          // rows of a patch slot (4 x 130 for 128-wide maps, 8 x 68 for 5x5 taps on 64-wide ones)
 constexpr int MT_PP_MAXTAPS = 25;
 
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     char* base = lds0 + slot * (STAGE * 16);
 #pragma unroll
     for (int j = 0; j < NWL; j++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j] + wk, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + (wvu + NW * j) * 1024), 16, wo32[j] + wk, 0, 0, PP_WEIGHT_AUX);
     tap_s += 1;
     const bool wrap = tap_s >= ntaps;
     sl_s = wrap ? sl_s + 1 : sl_s;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
 #pragma unroll
     for (int jj = 0; jj < NPW; jj++) off = (j == jj) ? xrow[jj] : off;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(ldsP + pslot * (PCAP * 64) + (wvu + NW * j) * 1024), 16,
-                                             off + (unsigned)sl * 64u, 0, 0, 0);
+                                             off + (unsigned)sl * 64u, 0, 0, PP_PATCH_AUX);
   };
 
   // FOLD: the virtual cells of patch slot `pslot` (its copies have landed and are visible), by the 256 threads of one

@@ -26,11 +26,13 @@ static int red_slot(hipStream_t s) {
   for (int i = 0; i < n; i++)
     if (tab[i] == s) return i;
   if (n < RED_SLOTS) { tab[n] = s; return n++; }
-  return -1;
+  // more streams than slots: share one by address (ordering between such streams is then the caller's business, as it was
+  // for every stream before round 3)
+  return (int)(((uintptr_t)s >> 6) % RED_SLOTS);
 }
 #define RED_SLOT_OR_FAIL(slot, s)                                                                     \
   const int slot = red_slot(s);                                                                       \
-  MT_CHECK(slot >= 0, "loss reductions: more than %d distinct streams in one process", RED_SLOTS)
+  MT_CHECK(slot >= 0 && slot < RED_SLOTS, "loss reductions: bad scratch slot %d", slot)
 __device__ __forceinline__ void grid_sum_to(float* dst, float v, int slot) {
   __shared__ float sw[4];
   __shared__ int last;
