@@ -116,6 +116,11 @@ size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d);
 /* dx = conv_bwd_data(dy).  dy is the gradient w.r.t. the pre-activation output. */
 int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx,
                      void* ws, size_t ws_bytes, mt_stream_t s);
+/* dx = data gradient + addend (a tensor of dx's shape and type; the skip-connection gradient of a residual block riding on
+ * its first convolution's data gradient: replaces autograd's separate accumulation pass).  Added inside the GEMM epilogue
+ * where the kernel supports it, by a separate in-place add otherwise; same workspace as mt_conv_bwd_data. */
+int mt_conv_bwd_data_add(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
+                         void* ws, size_t ws_bytes, mt_stream_t s);
 size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
 /* dw (reference layout, fp32), dbias (fp32 [Co]; may be NULL).  accumulate == 0: both are overwritten;
  * accumulate != 0: the gradients are ADDED to their current contents (lets the caller point dw/dbias at

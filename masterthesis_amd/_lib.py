@@ -54,6 +54,7 @@ SIGNATURES = {
     "mt_conv_fwd_stats": (_i, [_dp, _p, _p, _p, _p, _p, _p]),
     "mt_conv_bwd_data_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_data": (_i, [_dp, _p, _p, _p, _p, _z, _p]),
+    "mt_conv_bwd_data_add": (_i, [_dp, _p, _p, _p, _p, _p, _z, _p]),
     "mt_conv_bwd_weight_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_weight": (_i, [_dp, _p, _p, _p, _p, _p, _z, _i, _p]),
     "mt_conv_bwd_weight_partial": (_i, [_dp, _p, _p, _p, _p, _z, _i, _i, C.POINTER(C.c_int), _p]),

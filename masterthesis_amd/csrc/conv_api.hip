@@ -490,8 +490,10 @@ extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {
   return bwd_data_padded_bytes(d) + bwd_data_split_bytes(d);
 }
 
-extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, void* ws,
-                                size_t ws_bytes, mt_stream_t st) {
+// *added: set when `addend` went into the kernel's epilogue (else the caller adds it afterwards)
+static int conv_bwd_data_impl(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
+                              bool* added, void* ws, size_t ws_bytes, mt_stream_t st) {
+  *added = false;
   if (check_desc(d)) return 1;
   hipStream_t s = (hipStream_t)st;
   int Ho, Wo;
@@ -549,7 +551,11 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
     static const int fold_on = getenv("MT_IGEMM_FOLD") ? atoi(getenv("MT_IGEMM_FOLD")) : 1;
     if (fold_on && P == 1 && d->kh == 3 && d->kw == 3) {
       p.fold = 1;
-      if (mt_igemm_fold_ok(d->dtype, p)) return mt_launch_igemm(d->dtype, p, s) ? 2 : 0;
+      if (mt_igemm_fold_ok(d->dtype, p)) {
+        p.addend = (const char*)addend;
+        *added = addend != nullptr;
+        return mt_launch_igemm(d->dtype, p, s) ? 2 : 0;
+      }
       p.fold = 0;
     }
     if (mt_launch_igemm(d->dtype, p, s)) return 2;
@@ -571,6 +577,24 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
   if (rc == 100) return mt_launch_ring_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
   if (rc) return 2;
   return mt_launch_reflect_fold(d->dtype, ws, dx, d->N, d->H, d->W, Cip, P, s);
+}
+
+extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, void* ws,
+                                size_t ws_bytes, mt_stream_t st) {
+  bool added;
+  return conv_bwd_data_impl(d, dy, pack_bwd, dx, nullptr, &added, ws, ws_bytes, st);
+}
+// dx = data gradient + addend (a tensor of dx's shape and type, e.g. the skip-connection gradient of a residual block whose
+// first convolution this is): inside the GEMM epilogue where the kernel supports it (the patch-resident 256x256 kernel: one
+// extra read of the addend instead of a separate read-read-write pass), as a separate in-place add otherwise.
+extern "C" int mt_conv_bwd_data_add(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
+                                    void* ws, size_t ws_bytes, mt_stream_t st) {
+  MT_CHECK(addend != nullptr, "conv_bwd_data_add: null addend");
+  bool added;
+  const int rc = conv_bwd_data_impl(d, dy, pack_bwd, dx, addend, &added, ws, ws_bytes, st);
+  if (rc || added) return rc;
+  const size_t n = (size_t)d->N * d->H * d->W * mt_padc(d->Ci);
+  return mt_add(d->dtype, dx, addend, dx, n, st);
 }
 
 // pixel-split of the weight-gradient reduction: enough (tile, split) blocks to fill 256 CUs x 2

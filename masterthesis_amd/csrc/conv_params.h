@@ -53,6 +53,8 @@ struct IgemmParams {
   char* y2;           // optional second destination (persistent gather-GEMM only, mt_igemm_would_persist): output pixels
   int y2P, y2H, y2W;  // inside [y2P, y2P+y2H) x [y2P, y2P+y2W) of the (Hout, Wout) grid go to y2 -- an [N][y2H][y2W][Co] tensor,
                       // at (oh - y2P, ow - y2P) -- instead of y: the interior of a padded gradient map straight into dx
+  const char* addend; // optional tensor of the output's shape and type, added to the result in the epilogue (the residual
+                      // block's skip gradient riding on conv1's data gradient; conv_pipe_patch_kernel.hip only: mt_igemm_fold_ok)
   int fold;           // stride-1 3x3 gather over dy at offsets -1 .. 1 (the interior of a reflection-padded data gradient): also
                       // add the reflected ring inside the pixel operand (conv_pipe_patch_kernel.hip; mt_igemm_fold_ok)
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements

@@ -488,9 +488,23 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     for (int b = 0; b < FP; b++) {
       if (yp[b] == nullptr) continue;
       float v[8];
+      float ad[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) ad[e] = 0.f;
+      if (p.addend != nullptr) {
+        // (same offset as the store: the addend has the output's layout)
+        const char* ap = p.addend + (yp[b] - p.y) + (size_t)co * SZ;
+        if constexpr (BF16) {
+          Elem<true>::unpack(*reinterpret_cast<const u32x4*>(ap), ad);
+        } else {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 16);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { ad[e] = a0[e]; ad[4 + e] = a1[e]; }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope);
+        v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope) + ad[e];
         s1[e] += v[e];
         s2[e] += v[e] * v[e];
       }

@@ -412,6 +412,19 @@ class _oplog:
 # --------------------------------------------------------------------------------------
 # convolution family
 # --------------------------------------------------------------------------------------
+class GradLink:
+    """Carries the skip-connection gradient of a residual block from the normalisation that adds the residual (its backward
+    runs first) to the block's first convolution (its backward runs last): ``y = norm(conv2(..conv1(x)..), res=x)``.  With a
+    link, the norm's backward parks ``dy`` here instead of returning it as the gradient of ``res``, and conv1's backward
+    hands it to ``mt_conv_bwd_data_add`` -- the sum ``dgrad + dy`` is formed in the data-gradient GEMM's epilogue (or by the
+    library's add where that kernel does not apply) instead of by autograd's own accumulation pass over the three tensors
+    (``aten::add``: 0.6 ms per step).  Both ends must see the SAME tensor x (so both or neither need its gradient)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
@@ -458,6 +471,7 @@ class _Conv(torch.autograd.Function):
             _KTIMER["events"].append((e0, e1, N))
         ctx.desc = desc
         ctx.owner = owner
+        ctx.link = cfg[10] if len(cfg) > 10 else None
         ctx.bias_owner = bias
         # uses of this weight whose weight gradient is still to come in the backward pass under construction: when the
         # count returns to zero the parameter's gradient is final (it is accumulated straight into param.grad), which
@@ -513,9 +527,18 @@ class _Conv(torch.autograd.Function):
             nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dy.device)
             dx = new_act(*x.shape, dy.dtype, dy.device)
+            skip = None
+            if ctx.link is not None and ctx.link.g is not None:
+                skip, ctx.link.g = ctx.link.g, None
+                if skip.shape != dx.shape or skip.dtype != dx.dtype:
+                    raise RuntimeError("residual gradient link: the parked gradient does not match the block input")
             with _oplog("dgrad", desc):
-                L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
-                        "mt_conv_bwd_data")
+                if skip is not None:
+                    L.check(lib.mt_conv_bwd_data_add(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(skip), _ptr(ws), nws,
+                                                     _stream()), "mt_conv_bwd_data_add")
+                else:
+                    L.check(lib.mt_conv_bwd_data(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(ws), nws, _stream()),
+                            "mt_conv_bwd_data")
         need_b = want_b and not bias_done           # bias gradient still to be taken by the weight-gradient call
         if ctx.needs_input_grad[1] or need_b:
             nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
@@ -563,16 +586,18 @@ def set_grad_ready_hook(param, fn):
     param._mt_ready_hook = fn
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01, stats=False, bias_grad=True):
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01, stats=False, bias_grad=True,
+           grad_link=None):
     """act(conv2d(pad(x)) + bias): nn.ReflectionPad2d/zero pad + nn.Conv2d (+ activation).
 
     stats=True: also return the per-(image, channel) {sum, sum of squares} of the output, accumulated in the
     GEMM epilogue, for the normalisation layer that follows (pass it as ``sums=``).
     bias_grad=False: the bias is added but receives no gradient -- for a conv directly followed by an
-    affine-free InstanceNorm the bias gradient is identically zero (the reference computes round-off there)."""
+    affine-free InstanceNorm the bias gradient is identically zero (the reference computes round-off there).
+    grad_link: a ``GradLink`` shared with the normalisation that adds ``x`` back as a residual (see there)."""
     pm = L.PAD_REFLECT if (pad_mode == "reflect" and pad > 0) else L.PAD_ZERO
     return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0, bool(stats),
-                                         bool(bias_grad), torch.is_grad_enabled()))
+                                         bool(bias_grad), torch.is_grad_enabled(), grad_link))
 
 
 def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
@@ -851,17 +876,22 @@ class _Norm(torch.autograd.Function):
             dgamma = dgamma.view(gshape)
             dbeta = dbeta.view(bshape)
         dres = dy if ctx.needs_input_grad[4] else None
+        link = ctx.cfg[5] if len(ctx.cfg) > 5 else None
+        if link is not None and dres is not None:
+            link.g, dres = dres, None       # the block's first convolution adds it inside its data-gradient epilogue
         return dx, (dgb if mode == L.NORM_ADAIN else None), dgamma, dbeta, dres, None, None
 
 
-def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
+def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act(InstanceNorm2d(affine=False)(x)) (+ res); ``sums`` = statistics from conv2d(..., stats=True)"""
-    return _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps)))
+    return _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps), None,
+                                                        res_link if res is not None else None))
 
 
-def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None):
+def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
-    return _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps)))
+    return _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps), None,
+                                                      res_link if res is not None else None))
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, act=None, slope=0.01,

@@ -71,20 +71,23 @@ class ConvBlock(nn.Module):
             mods.append(_Marker(self.act))
         self.block = nn.Sequential(*mods)
 
-    def forward(self, x, res=None, want_stats=False):
-        """want_stats: return (conv output, its normalisation statistics) for an external norm layer (AdaIN)."""
+    def forward(self, x, res=None, want_stats=False, grad_link=None, res_link=None):
+        """want_stats: return (conv output, its normalisation statistics) for an external norm layer (AdaIN).
+        grad_link / res_link: the two ends of a residual block's ``ops.GradLink`` -- this block is the first convolution of
+        the residual branch (its data gradient takes the skip gradient along), resp. the block whose norm adds ``res``."""
         conv = self.block[self._ci]
         weight = conv_weight(conv, self.training)
         if want_stats:
             assert self.norm is None and self.act is None and res is None
             return ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
-                              pad_mode=self.pad_mode, stats=True)
+                              pad_mode=self.pad_mode, stats=True, grad_link=grad_link)
         if self.norm == "instance":
             # statistics come out of the GEMM epilogue; the bias in front of an affine-free InstanceNorm has an
             # identically zero gradient (SURVEY.md Appendix D-4), so none is computed
             y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
-                                 pad_mode=self.pad_mode, stats=True, bias_grad=False)
-            return ops.instance_norm_act(y, act=self.act, res=res, sums=sums)
+                                 pad_mode=self.pad_mode, stats=True, bias_grad=False, grad_link=grad_link)
+            return ops.instance_norm_act(y, act=self.act, res=res, sums=sums, res_link=res_link)
+        assert grad_link is None and res_link is None, "residual gradient links are wired for the instance-norm blocks only"
         if self.norm == "batch":
             if self.training:
                 y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
@@ -195,6 +198,10 @@ class ResnetBlock(nn.Module):
     def forward(self, x):
         if len(self.model) > 2 and self.training:
             return ops.add(self.model[2](self.model[1](self.model[0](x))), x)
+        if self.model[0].norm == "instance" and self.model[1].norm == "instance":
+            # the skip gradient rides on the first convolution's data gradient instead of autograd's accumulation pass
+            link = ops.GradLink()
+            return self.model[1](self.model[0](x, grad_link=link), res=x, res_link=link)
         return self.model[1](self.model[0](x), res=x)
 
 
@@ -216,12 +223,14 @@ class AdaINResnetBlock(nn.Module):
         # projection it computed for all of its blocks in one launch
         if gb is None:
             gb = self.norm.project(z)
-        y, sums = self.conv1(x, want_stats=True)
+        plain = not (isinstance(self.dropout, Dropout) and self.training)
+        link = ops.GradLink() if plain else None         # (the skip gradient rides on conv1's data gradient)
+        y, sums = self.conv1(x, want_stats=True, grad_link=link)
         h = self.norm(y, z, act=self.act, sums=sums, gb=gb)
         y, sums = self.conv2(h, want_stats=True)
-        if isinstance(self.dropout, Dropout) and self.training:
+        if not plain:
             return ops.add(self.dropout(self.norm(y, z, sums=sums, gb=gb)), x)     # (the add cannot ride on the norm pass)
-        return self.norm(y, z, res=x, sums=sums, gb=gb)
+        return self.norm(y, z, res=x, sums=sums, gb=gb, res_link=link)
 
 
 def _expand_planes(v, ref):

@@ -37,6 +37,6 @@ class AdaptiveInstanceNorm(nn.Module):
         """[w, b] = fc(s); a block that normalises twice with the same style (blocks.py:152-164) projects once"""
         return ops.linear(s, self.fc.weight, self.fc.bias)
 
-    def forward(self, x, s, act=None, res=None, sums=None, gb=None):
+    def forward(self, x, s, act=None, res=None, sums=None, gb=None, res_link=None):
         h = self.project(s) if gb is None else gb
-        return ops.adain_act(x, h, act=act, res=res, sums=sums)
+        return ops.adain_act(x, h, act=act, res=res, sums=sums, res_link=res_link)

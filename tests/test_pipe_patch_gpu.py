@@ -92,3 +92,36 @@ def test_patch_resident_ping_pong_is_bit_identical_to_the_ring_kernel(case, hip_
         yr.backward(gy)
         assert ((y1 - yr.detach()).norm() / yr.detach().norm()).item() < 1e-5
         assert ((dx1 - xr.grad).norm() / xr.grad.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_skip_gradient_rides_on_the_data_gradient_epilogue(dtype, hip_device):
+    """ops.GradLink: the skip-connection gradient parked by the residual norm's backward is added inside the epilogue of
+    conv1's data-gradient GEMM (mt_conv_bwd_data_add on the patch-resident kernel) -- dx must be dgrad + skip, to one
+    rounding of the sum (bf16) / to summation order (fp32) -- and through the library's add where the kernel does not apply."""
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    ops.set_compute_dtype(dtype)
+    lib = L.load()
+    try:
+        for (N, C, H) in ((16, 256, 64), (2, 24, 20)):          # fused epilogue / fallback add
+            g = torch.Generator().manual_seed(N + C)
+            x = torch.randn(N, C, H, H, generator=g).bfloat16().float().to(hip_device)
+            w = (torch.randn(C, C, 3, 3, generator=g) * (C * 9) ** -0.5).bfloat16().float().to(hip_device)
+            gy = ops.canon(torch.randn(N, C, H, H, generator=g).bfloat16().float().to(hip_device))
+            skip = ops.canon(torch.randn(N, C, H, H, generator=g).bfloat16().float().to(hip_device))
+            xa = x.clone().requires_grad_()
+            ops.conv2d(xa, w, None, stride=1, pad=1, pad_mode="reflect").backward(gy)
+            link = ops.GradLink()
+            xb = x.clone().requires_grad_()
+            n0 = lib.mt_kernel_variant_launches(3)
+            y = ops.conv2d(xb, w, None, stride=1, pad=1, pad_mode="reflect", grad_link=link)
+            link.g = skip
+            y.backward(gy)
+            used = lib.mt_kernel_variant_launches(3) - n0
+            assert link.g is None and used == (2 if C == 256 else 0)
+            want = ops.to_nchw_f32(xa.grad) + ops.to_nchw_f32(skip)
+            got = ops.to_nchw_f32(xb.grad)
+            tol = 2 ** -8 if dtype == torch.bfloat16 else 1e-5
+            assert (got - want).abs().max().item() <= tol * want.abs().max().item() + 1e-6
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
