@@ -121,6 +121,22 @@ int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const void* pack_bwd
  * where the kernel supports it, by a separate in-place add otherwise; same workspace as mt_conv_bwd_data. */
 int mt_conv_bwd_data_add(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
                          void* ws, size_t ws_bytes, mt_stream_t s);
+/* ... and the statistics of the normalisation BACKWARD that consumes dx, taken in the same epilogue (the sums mt_nc_stats_bwd
+ * would compute in a pass of its own over dx and x):  with g = dx * act'(scale[n][c] * x + shift[n][c]),
+ * sums[n][c] += {sum g, sum g * x} over the pixels.  x: the norm's input (dx's shape and type); scale / shift: the fp32 [N][Cp]
+ * coefficients of its forward; sums: fp32 [N][Cp][2], MUST BE ZERO on entry (float atomics: not in deterministic runs).
+ * *stats_done = 1 if the kernel that ran produced them (the patch-resident 256x256 kernel), 0 if the caller still has to
+ * run mt_nc_stats_bwd.  addend and bs may each be NULL. */
+typedef struct mt_bwd_stats {
+  const void* x;
+  const float* scale;
+  const float* shift;
+  float* sums;
+  int act;
+  float slope;
+} mt_bwd_stats;
+int mt_conv_bwd_data_ex(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
+                        const mt_bwd_stats* bs, int* stats_done, void* ws, size_t ws_bytes, mt_stream_t s);
 size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
 /* dw (reference layout, fp32), dbias (fp32 [Co]; may be NULL).  accumulate == 0: both are overwritten;
  * accumulate != 0: the gradients are ADDED to their current contents (lets the caller point dw/dbias at

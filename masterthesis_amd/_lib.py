@@ -32,6 +32,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BwdStats(C.Structure):
+    """mirror of ``mt_bwd_stats``"""
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("sums", C.c_void_p),
+                ("act", C.c_int), ("slope", C.c_float)]
+
+
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _i64, _u64 = C.c_int64, C.c_uint64
 _dp = C.POINTER(ConvDesc)
@@ -55,6 +61,7 @@ SIGNATURES = {
     "mt_conv_bwd_data_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_data": (_i, [_dp, _p, _p, _p, _p, _z, _p]),
     "mt_conv_bwd_data_add": (_i, [_dp, _p, _p, _p, _p, _p, _z, _p]),
+    "mt_conv_bwd_data_ex": (_i, [_dp, _p, _p, _p, _p, C.POINTER(BwdStats), C.POINTER(C.c_int), _p, _z, _p]),
     "mt_conv_bwd_weight_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_weight": (_i, [_dp, _p, _p, _p, _p, _p, _z, _i, _p]),
     "mt_conv_bwd_weight_partial": (_i, [_dp, _p, _p, _p, _p, _z, _i, _i, C.POINTER(C.c_int), _p]),

@@ -492,8 +492,10 @@ extern "C" size_t mt_conv_bwd_data_ws_bytes(const mt_conv_desc* d) {
 
 // *added: set when `addend` went into the kernel's epilogue (else the caller adds it afterwards)
 static int conv_bwd_data_impl(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
-                              bool* added, void* ws, size_t ws_bytes, mt_stream_t st) {
+                              bool* added, void* ws, size_t ws_bytes, mt_stream_t st, const mt_bwd_stats* bs = nullptr,
+                              bool* stats_done = nullptr) {
   *added = false;
+  if (stats_done) *stats_done = false;
   if (check_desc(d)) return 1;
   hipStream_t s = (hipStream_t)st;
   int Ho, Wo;
@@ -554,6 +556,11 @@ static int conv_bwd_data_impl(const mt_conv_desc* d, const void* dy, const void*
       if (mt_igemm_fold_ok(d->dtype, p)) {
         p.addend = (const char*)addend;
         *added = addend != nullptr;
+        if (bs != nullptr && bs->x != nullptr && bs->sums != nullptr) {
+          p.stats = bs->sums; p.bstat_x = (const char*)bs->x; p.bstat_scale = bs->scale; p.bstat_shift = bs->shift;
+          p.bstat_act = bs->act; p.bstat_slope = bs->slope;
+          if (stats_done) *stats_done = true;
+        }
         return mt_launch_igemm(d->dtype, p, s) ? 2 : 0;
       }
       p.fold = 0;
@@ -589,10 +596,18 @@ extern "C" int mt_conv_bwd_data(const mt_conv_desc* d, const void* dy, const voi
 // extra read of the addend instead of a separate read-read-write pass), as a separate in-place add otherwise.
 extern "C" int mt_conv_bwd_data_add(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
                                     void* ws, size_t ws_bytes, mt_stream_t st) {
-  MT_CHECK(addend != nullptr, "conv_bwd_data_add: null addend");
-  bool added;
-  const int rc = conv_bwd_data_impl(d, dy, pack_bwd, dx, addend, &added, ws, ws_bytes, st);
-  if (rc || added) return rc;
+  return mt_conv_bwd_data_ex(d, dy, pack_bwd, dx, addend, nullptr, nullptr, ws, ws_bytes, st);
+}
+// ... and, where the kernel supports it, the statistics of the normalisation backward that consumes dx (mt_bwd_stats):
+// *stats_done = 1 when bs->sums was filled (else the caller runs mt_nc_stats_bwd as usual).  addend may be NULL.
+extern "C" int mt_conv_bwd_data_ex(const mt_conv_desc* d, const void* dy, const void* pack_bwd, void* dx, const void* addend,
+                                   const mt_bwd_stats* bs, int* stats_done, void* ws, size_t ws_bytes, mt_stream_t st) {
+  bool added, sdone;
+  if (stats_done) *stats_done = 0;
+  const int rc = conv_bwd_data_impl(d, dy, pack_bwd, dx, addend, &added, ws, ws_bytes, st, bs, &sdone);
+  if (rc) return rc;
+  if (stats_done) *stats_done = sdone ? 1 : 0;
+  if (addend == nullptr || added) return 0;
   const size_t n = (size_t)d->N * d->H * d->W * mt_padc(d->Ci);
   return mt_add(d->dtype, dx, addend, dx, n, st);
 }

@@ -494,7 +494,7 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
     const int r = launch_igemm_pipe_patch_t<BF16>(p, total, s, dry);
     if (r >= 0) return r;
   }
-  if (p.fold || p.addend != nullptr) {
+  if (p.fold || p.addend != nullptr || p.bstat_x != nullptr) {
     if (dry) return 101;
     mt_set_error("igemm: the in-operand reflection fold / epilogue addend need the patch-resident 256x256 kernel (mt_igemm_fold_ok)");
     return 1;

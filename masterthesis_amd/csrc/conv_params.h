@@ -55,6 +55,14 @@ struct IgemmParams {
                       // at (oh - y2P, ow - y2P) -- instead of y: the interior of a padded gradient map straight into dx
   const char* addend; // optional tensor of the output's shape and type, added to the result in the epilogue (the residual
                       // block's skip gradient riding on conv1's data gradient; conv_pipe_patch_kernel.hip only: mt_igemm_fold_ok)
+  // optional statistics of the normalisation BACKWARD whose gradient this launch produces (conv_pipe_patch_kernel.hip only):
+  // with g = out * act'(bstat_scale * x + bstat_shift), stats[n][c] += {sum g, sum g * x} over the pixels (x = bstat_x: the
+  // norm's input, same shape / type as the output; scale, shift: fp32 [N][Co]); `stats` is then that output, zero on entry
+  const char* bstat_x;
+  const float* bstat_scale;
+  const float* bstat_shift;
+  int bstat_act;
+  float bstat_slope;
   int fold;           // stride-1 3x3 gather over dy at offsets -1 .. 1 (the interior of a reflection-padded data gradient): also
                       // add the reflected ring inside the pixel operand (conv_pipe_patch_kernel.hip; mt_igemm_fold_ok)
   int raw;            // split-K: write the fp32 accumulators as they are (no bias / activation, fp32 elements

@@ -484,6 +484,15 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
+    const bool bstat = p.bstat_x != nullptr;
+    float bsc[8], bsh[8];
+    if (bstat) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(p.bstat_scale + (size_t)n0 * p.Co + co);
+      const f32x4* r = reinterpret_cast<const f32x4*>(p.bstat_shift + (size_t)n0 * p.Co + co);
+      const f32x4 q0 = q[0], q1 = q[1], r0 = r[0], r1 = r[1];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { bsc[e] = q0[e]; bsc[4 + e] = q1[e]; bsh[e] = r0[e]; bsh[4 + e] = r1[e]; }
+    }
 #pragma unroll
     for (int b = 0; b < FP; b++) {
       if (yp[b] == nullptr) continue;
@@ -503,10 +512,27 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope) + ad[e];
-        s1[e] += v[e];
-        s2[e] += v[e] * v[e];
+      for (int e = 0; e < 8; e++) v[e] = act_apply(acc[2 * sp + (e >> 2)][b][e & 3] + bv[e], p.act, p.slope) + ad[e];
+      if (bstat) {
+        // statistics of the normalisation backward that consumes this gradient: g = v * act'(scale * x + shift)
+        float xx[8];
+        const char* xp = p.bstat_x + (yp[b] - p.y) + (size_t)co * SZ;
+        if constexpr (BF16) {
+          Elem<true>::unpack(*reinterpret_cast<const u32x4*>(xp), xx);
+        } else {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(xp), a1 = *reinterpret_cast<const f32x4*>(xp + 16);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { xx[e] = a0[e]; xx[4 + e] = a1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float gg = v[e] * act_grad_z(bsc[e] * xx[e] + bsh[e], p.bstat_act, p.bstat_slope);
+          s1[e] += gg;
+          s2[e] += gg * xx[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       }
       if constexpr (BF16) {
         u32x4 o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
@@ -583,7 +609,7 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
   if (p.fold) {
     // the in-operand fold is written for a 3x3 window at offsets -1 .. 1 on a map of the output's size (pad 1)
     if (q.ntaps != 9 || dhmin != -1 || dhmax != 1 || dwmin != -1 || dwmax != 1 || p.Hi < 4 || p.Wi < 4 || p.Hi != Ho || p.Wi != Wo ||
-        p.pad_mode != MT_PAD_ZERO || p.os != 1 || p.stats != nullptr)
+        p.pad_mode != MT_PAD_ZERO || p.os != 1 || (p.stats != nullptr && p.bstat_x == nullptr))
       return -1;
     // the virtual cells live behind the patch rows; the next slice's copies must all be out by step 3 (they are built in step 6)
     if (PH * PW + 2 * PH + 2 * (PW + 2) > MT_PP_PCAP || nmine > 4) return -1;

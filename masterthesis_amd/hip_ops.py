@@ -425,6 +425,28 @@ class GradLink:
         self.g = None
 
 
+class StatsLink:
+    """Hands the statistics pass of a normalisation BACKWARD to the kernel that produces its gradient.  A norm whose output
+    y is consumed by a residual block only -- the block's first convolution plus the skip -- gets its whole gradient
+    ``dy = dgrad(conv1) + skip`` out of conv1's data-gradient epilogue (GradLink), and a norm in front of a plain
+    convolution gets ``dy = dgrad(conv)``; the sums the norm's backward needs, {sum g, sum g * x} with g = dy * act'(..),
+    can be taken right there (``mt_conv_bwd_data_ex``) instead of in a pass of their own over dy and x (``mt_nc_stats_bwd``:
+    63 launches, 1.7 ms per step).  The norm's forward fills ``x, scale, shift, act, slope`` and hangs the link on its
+    output tensor (``y._mt_stats_link``); a consumer that is the ONLY path of y's gradient passes it to ``conv2d(...,
+    bwd_stats=link)``; the convolution's backward leaves ``sums`` here when the kernel that ran could produce them, and the
+    norm's backward then skips its statistics pass.  Any other situation falls back to the norm's own pass."""
+    __slots__ = ("x", "scale", "shift", "act", "slope", "sums")
+
+    def __init__(self):
+        self.x = self.scale = self.shift = self.sums = None
+        self.act, self.slope = 0, 0.0
+
+
+def stats_link_of(t):
+    """the StatsLink a normalisation hung on its output tensor, if any (and fused statistics are allowed at all)"""
+    return None if _DETERMINISTIC[0] else getattr(t, "_mt_stats_link", None)
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
@@ -472,6 +494,7 @@ class _Conv(torch.autograd.Function):
         ctx.desc = desc
         ctx.owner = owner
         ctx.link = cfg[10] if len(cfg) > 10 else None
+        ctx.bstats = cfg[11] if len(cfg) > 11 else None
         ctx.bias_owner = bias
         # uses of this weight whose weight gradient is still to come in the backward pass under construction: when the
         # count returns to zero the parameter's gradient is final (it is accumulated straight into param.grad), which
@@ -532,8 +555,18 @@ class _Conv(torch.autograd.Function):
                 skip, ctx.link.g = ctx.link.g, None
                 if skip.shape != dx.shape or skip.dtype != dx.dtype:
                     raise RuntimeError("residual gradient link: the parked gradient does not match the block input")
+            bl = ctx.bstats
+            if bl is not None and (bl.x is None or _DETERMINISTIC[0] or bl.x.shape != dx.shape or bl.x.dtype != dx.dtype):
+                bl = None
             with _oplog("dgrad", desc):
-                if skip is not None:
+                if bl is not None:
+                    sums2 = _zero_stats((x.shape[0], padc(x.shape[1]), 2), dy.device)
+                    bs = L.BwdStats(_ptr(bl.x), _ptr(bl.scale), _ptr(bl.shift), _ptr(sums2), int(bl.act), float(bl.slope))
+                    done = C.c_int(0)
+                    L.check(lib.mt_conv_bwd_data_ex(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(skip), C.byref(bs),
+                                                    C.byref(done), _ptr(ws), nws, _stream()), "mt_conv_bwd_data_ex")
+                    bl.sums = sums2 if done.value else None
+                elif skip is not None:
                     L.check(lib.mt_conv_bwd_data_add(C.byref(desc), _ptr(dy), _ptr(pack), _ptr(dx), _ptr(skip), _ptr(ws), nws,
                                                      _stream()), "mt_conv_bwd_data_add")
                 else:
@@ -587,17 +620,19 @@ def set_grad_ready_hook(param, fn):
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act=None, slope=0.01, stats=False, bias_grad=True,
-           grad_link=None):
+           grad_link=None, bwd_stats=None):
     """act(conv2d(pad(x)) + bias): nn.ReflectionPad2d/zero pad + nn.Conv2d (+ activation).
 
     stats=True: also return the per-(image, channel) {sum, sum of squares} of the output, accumulated in the
     GEMM epilogue, for the normalisation layer that follows (pass it as ``sums=``).
     bias_grad=False: the bias is added but receives no gradient -- for a conv directly followed by an
     affine-free InstanceNorm the bias gradient is identically zero (the reference computes round-off there).
-    grad_link: a ``GradLink`` shared with the normalisation that adds ``x`` back as a residual (see there)."""
+    grad_link: a ``GradLink`` shared with the normalisation that adds ``x`` back as a residual (see there).
+    bwd_stats: the ``StatsLink`` of the normalisation that produced ``x``, when this convolution (+ grad_link) is the only
+    path of x's gradient: its data gradient then also delivers that norm's backward statistics."""
     pm = L.PAD_REFLECT if (pad_mode == "reflect" and pad > 0) else L.PAD_ZERO
     return _Conv.apply(x, weight, bias, (stride, pad, pm, _act_code(act), float(slope), False, 0, bool(stats),
-                                         bool(bias_grad), torch.is_grad_enabled(), grad_link))
+                                         bool(bias_grad), torch.is_grad_enabled(), grad_link, bwd_stats))
 
 
 def conv_transpose2d(x, weight, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
@@ -831,6 +866,10 @@ class _Norm(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(x, coef, gbc, gm)
         ctx.shapes = (None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+        sl = cfg[6] if len(cfg) > 6 else None          # StatsLink created by the wrapper (it hangs it on the output tensor)
+        if sl is not None:
+            sl.x, sl.scale, sl.shift, sl.act, sl.slope = x, coef[0], coef[1], act, slope
+        ctx.slink = sl
         return y
 
     @staticmethod
@@ -843,11 +882,17 @@ class _Norm(torch.autograd.Function):
         Cp, HW = padc(Cc), H * W
         dev = x.device
         mt = _mt(x.dtype)
-        nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
-        sums2 = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)
-        with _hbm("nc_stats_bwd", N * HW * Cp * x.element_size() * 2):
-            L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
-                                        slope, _stream()), "mt_nc_stats_bwd")
+        sl = ctx.slink
+        if sl is not None and sl.sums is not None and tuple(sl.sums.shape) == (N, Cp, 2):
+            # the kernel that produced dy took the sums in its epilogue (StatsLink): one partial row per image
+            sums2, nparts = sl.sums, 1
+            sl.sums = None
+        else:
+            nparts = int(lib.mt_nc_stats_parts(mt, N, HW, Cp))
+            sums2 = torch.empty((N, nparts, Cp, 2), dtype=torch.float32, device=dev)
+            with _hbm("nc_stats_bwd", N * HW * Cp * x.element_size() * 2):
+                L.check(lib.mt_nc_stats_bwd(mt, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(sums2), N, HW, Cp, act,
+                                            slope, _stream()), "mt_nc_stats_bwd")
         cc = torch.empty((3, N, Cp), dtype=torch.float32, device=dev)
         dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
         dgamma = dbeta = None
@@ -884,14 +929,22 @@ class _Norm(torch.autograd.Function):
 
 def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act(InstanceNorm2d(affine=False)(x)) (+ res); ``sums`` = statistics from conv2d(..., stats=True)"""
-    return _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps), None,
-                                                        res_link if res is not None else None))
+    sl = StatsLink() if (torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
+    y = _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps), None,
+                                                     res_link if res is not None else None, sl))
+    if sl is not None:
+        y._mt_stats_link = sl
+    return y
 
 
 def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
-    return _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps), None,
-                                                      res_link if res is not None else None))
+    sl = StatsLink() if (torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
+    y = _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps), None,
+                                                   res_link if res is not None else None, sl))
+    if sl is not None:
+        y._mt_stats_link = sl
+    return y
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, act=None, slope=0.01,

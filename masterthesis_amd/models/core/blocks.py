@@ -71,7 +71,7 @@ class ConvBlock(nn.Module):
             mods.append(_Marker(self.act))
         self.block = nn.Sequential(*mods)
 
-    def forward(self, x, res=None, want_stats=False, grad_link=None, res_link=None):
+    def forward(self, x, res=None, want_stats=False, grad_link=None, res_link=None, bwd_stats=None):
         """want_stats: return (conv output, its normalisation statistics) for an external norm layer (AdaIN).
         grad_link / res_link: the two ends of a residual block's ``ops.GradLink`` -- this block is the first convolution of
         the residual branch (its data gradient takes the skip gradient along), resp. the block whose norm adds ``res``."""
@@ -80,14 +80,15 @@ class ConvBlock(nn.Module):
         if want_stats:
             assert self.norm is None and self.act is None and res is None
             return ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
-                              pad_mode=self.pad_mode, stats=True, grad_link=grad_link)
+                              pad_mode=self.pad_mode, stats=True, grad_link=grad_link, bwd_stats=bwd_stats)
         if self.norm == "instance":
             # statistics come out of the GEMM epilogue; the bias in front of an affine-free InstanceNorm has an
             # identically zero gradient, so none is computed
             y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding,
-                                 pad_mode=self.pad_mode, stats=True, bias_grad=False, grad_link=grad_link)
+                                 pad_mode=self.pad_mode, stats=True, bias_grad=False, grad_link=grad_link, bwd_stats=bwd_stats)
             return ops.instance_norm_act(y, act=self.act, res=res, sums=sums, res_link=res_link)
-        assert grad_link is None and res_link is None, "residual gradient links are wired for the instance-norm blocks only"
+        assert grad_link is None and res_link is None and bwd_stats is None, \
+            "residual gradient / statistics links are wired for the instance-norm blocks only"
         if self.norm == "batch":
             if self.training:
                 y, sums = ops.conv2d(x, weight, conv.bias, stride=self.stride, pad=self.padding, pad_mode=self.pad_mode,
@@ -201,7 +202,10 @@ class ResnetBlock(nn.Module):
         if self.model[0].norm == "instance" and self.model[1].norm == "instance":
             # the skip gradient rides on the first convolution's data gradient instead of autograd's accumulation pass
             link = ops.GradLink()
-            return self.model[1](self.model[0](x, grad_link=link), res=x, res_link=link)
+            # x's gradient is formed entirely in conv1's data-gradient epilogue (dgrad + skip): if a normalisation produced
+            # x, its backward statistics come out of that epilogue too; likewise conv2 for the norm in between
+            h = self.model[0](x, grad_link=link, bwd_stats=ops.stats_link_of(x))
+            return self.model[1](h, res=x, res_link=link, bwd_stats=ops.stats_link_of(h))
         return self.model[1](self.model[0](x), res=x)
 
 
@@ -225,9 +229,9 @@ class AdaINResnetBlock(nn.Module):
             gb = self.norm.project(z)
         plain = not (isinstance(self.dropout, Dropout) and self.training)
         link = ops.GradLink() if plain else None         # (the skip gradient rides on conv1's data gradient)
-        y, sums = self.conv1(x, want_stats=True, grad_link=link)
+        y, sums = self.conv1(x, want_stats=True, grad_link=link, bwd_stats=ops.stats_link_of(x) if plain else None)
         h = self.norm(y, z, act=self.act, sums=sums, gb=gb)
-        y, sums = self.conv2(h, want_stats=True)
+        y, sums = self.conv2(h, want_stats=True, bwd_stats=ops.stats_link_of(h))
         if not plain:
             return ops.add(self.dropout(self.norm(y, z, sums=sums, gb=gb)), x)     # (the add cannot ride on the norm pass)
         return self.norm(y, z, res=x, sums=sums, gb=gb, res_link=link)

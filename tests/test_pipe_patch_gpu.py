@@ -125,3 +125,44 @@ def test_skip_gradient_rides_on_the_data_gradient_epilogue(dtype, hip_device):
             assert (got - want).abs().max().item() <= tol * want.abs().max().item() + 1e-6
     finally:
         ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)], ids=["fp32", "bf16"])
+def test_norm_backward_statistics_from_the_data_gradient_epilogue(dtype, tol, hip_device):
+    """A chain [conv-IN-ReLU] -> ResnetBlock -> ResnetBlock at the step's size (256 channels, 64x64, 16 images): with the
+    gradient / statistics links the skip gradients are added and the sums of five of the six normalisation backwards are
+    taken inside the data-gradient epilogues (ops.GradLink / ops.StatsLink, mt_conv_bwd_data_ex); deterministic mode runs
+    every statistics pass on its own.  Same gradients either way."""
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd.models.core import blocks as B
+    from masterthesis_amd.models.core.functions import init_weights
+    import torch.nn as nn
+    ops.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(1)
+        net = nn.Sequential(B.ConvBlock(256, 256, 3, 1, 1, padding_type="reflect", norm_layer="instance", activation="relu"),
+                            B.ResnetBlock(256, 256), B.ResnetBlock(256, 256))
+        init_weights(net, "normal", 0.05)
+        net = net.to(hip_device)
+        x0 = torch.randn(16, 256, 64, 64, generator=torch.Generator().manual_seed(2)).to(hip_device)
+        gy = ops.canon(torch.randn(16, 256, 64, 64, generator=torch.Generator().manual_seed(3)).to(hip_device))
+        res = {}
+        for det in (True, False):
+            ops.set_deterministic(det)
+            for p in net.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            y = net(x)
+            ops.hbm_timer_start()
+            y.backward(gy)
+            calls = ops.hbm_timer_stop().get("nc_stats_bwd", (0, 0, 0))[0]
+            res[det] = (ops.to_nchw_f32(x.grad).cpu(), [p.grad.detach().cpu().clone() for p in net.parameters()], calls)
+        assert res[True][2] == 5 and res[False][2] == 1, (res[True][2], res[False][2])     # only the last norm keeps its own pass
+        a, b = res[False], res[True]
+        assert ((a[0] - b[0]).norm() / b[0].norm()).item() < tol
+        for ga, gb in zip(a[1], b[1]):
+            if gb.norm().item() > 1e-6 * max(g.norm().item() for g in b[1]):
+                assert ((ga - gb).norm() / gb.norm()).item() < tol
+    finally:
+        ops.set_deterministic(False)
+        ops.set_compute_dtype(torch.bfloat16)
