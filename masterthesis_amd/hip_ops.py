@@ -442,9 +442,12 @@ class StatsLink:
         self.act, self.slope = 0, 0.0
 
 
+_STATS_LINK_ON = [os.environ.get("MT_STATS_LINK", "1") != "0"]
+
+
 def stats_link_of(t):
     """the StatsLink a normalisation hung on its output tensor, if any (and fused statistics are allowed at all)"""
-    return None if _DETERMINISTIC[0] else getattr(t, "_mt_stats_link", None)
+    return None if (_DETERMINISTIC[0] or not _STATS_LINK_ON[0]) else getattr(t, "_mt_stats_link", None)
 
 
 class _Conv(torch.autograd.Function):

