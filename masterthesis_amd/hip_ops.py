@@ -442,7 +442,15 @@ class StatsLink:
         self.act, self.slope = 0, 0.0
 
 
-_STATS_LINK_ON = [os.environ.get("MT_STATS_LINK", "1") != "0"]
+# Off by default: measured same-box (round 3), the data-gradient epilogue -- the one moment when all 256 CUs hit HBM
+# together -- grows by 17 us per K1 launch for the extra tile read, the stand-alone statistics pass it replaces costs 27 us
+# in isolation, and the step does not move (36.63-36.82 vs 36.65-36.71 ms): the pass it removes was also what pulled x into
+# the Infinity Cache for the apply pass that follows.  MT_STATS_LINK=1 / set_stats_link(True) turn it on.
+_STATS_LINK_ON = [os.environ.get("MT_STATS_LINK", "0") == "1"]
+
+
+def set_stats_link(on):
+    _STATS_LINK_ON[0] = bool(on)
 
 
 def stats_link_of(t):
@@ -932,7 +940,7 @@ class _Norm(torch.autograd.Function):
 
 def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act(InstanceNorm2d(affine=False)(x)) (+ res); ``sums`` = statistics from conv2d(..., stats=True)"""
-    sl = StatsLink() if (torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
+    sl = StatsLink() if (_STATS_LINK_ON[0] and torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
     y = _Norm.apply(x, None, None, None, res, sums, (L.NORM_INSTANCE, _act_code(act), float(slope), float(eps), None,
                                                      res_link if res is not None else None, sl))
     if sl is not None:
@@ -942,7 +950,7 @@ def instance_norm_act(x, act=None, slope=0.01, res=None, eps=1e-5, sums=None, re
 
 def adain_act(x, gb, act=None, slope=0.01, res=None, eps=1e-5, sums=None, res_link=None):
     """act((1 + gb[:, :C]) * IN(x) + gb[:, C:]) (+ res)  -- reference norm.py:29-33"""
-    sl = StatsLink() if (torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
+    sl = StatsLink() if (_STATS_LINK_ON[0] and torch.is_grad_enabled() and not _DETERMINISTIC[0]) else None
     y = _Norm.apply(x, gb, None, None, res, sums, (L.NORM_ADAIN, _act_code(act), float(slope), float(eps), None,
                                                    res_link if res is not None else None, sl))
     if sl is not None:

@@ -151,6 +151,7 @@ def test_norm_backward_statistics_from_the_data_gradient_epilogue(dtype, tol, hi
         x0 = torch.randn(16, 256, 64, 64, generator=torch.Generator().manual_seed(2)).to(hip_device)
         gy = ops.canon(torch.randn(16, 256, 64, 64, generator=torch.Generator().manual_seed(3)).to(hip_device))
         res = {}
+        ops.set_stats_link(True)
         for det in (True, False):
             ops.set_deterministic(det)
             for p in net.parameters():
@@ -169,4 +170,5 @@ def test_norm_backward_statistics_from_the_data_gradient_epilogue(dtype, tol, hi
                 assert ((ga - gb).norm() / gb.norm()).item() < tol
     finally:
         ops.set_deterministic(False)
+        ops.set_stats_link(False)
         ops.set_compute_dtype(torch.bfloat16)
