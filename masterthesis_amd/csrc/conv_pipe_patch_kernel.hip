@@ -176,33 +176,6 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     f_cR[b] = FOLD && (c0 + fr) == ph_Wo - 2;
   }
 
-  // TAPS9: LDS byte offset (from the start of the shared array, patch slot 0; slot 1 is a constant further, which fits
-  // the DS instruction's 16-bit immediate) of this lane's chunk of fragment b at tap t
-  int qa[9][FP];
-  if constexpr (TAPS9) {
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const int dh = (int)p.dh[ph.tap0 + t], dw = (int)p.dw[ph.tap0 + t];
-      const int qo = (dh - dh0) * PW + (dw - dw0);
-#pragma unroll
-      for (int b = 0; b < FP; b++) {
-        int q = q0[b] + qo;
-        if constexpr (FOLD) {
-          const bool rh = dh > 0 ? f_rT[b] : (dh < 0 ? f_rB[b] : false);
-          const bool ch = dw > 0 ? f_hasL[b] : (dw < 0 ? f_hasR[b] : false);
-          const int vrow = dh > 0 ? vT0 : vB0;
-          if (rh) q = vrow + f_lx[b] + dw + 1;                                      // VT / VB cell of column v + dw
-          if (ch) {
-            const bool cl = dw > 0 ? f_cL[b] : f_cR[b];                             // this lane's pixel is the column
-            const int alt = rh ? vrow + PW + (dw > 0 ? 0 : 1) : (dw > 0 ? vL0 : vR0) + f_ly[b] + dh + 1;
-            q = cl ? alt : q;
-          }
-        }
-        qa[t][b] = (NS * STAGE + q * 4 + (fg ^ ((q >> 1) & 3))) * 16;
-      }
-    }
-  }
-
   // ---- weight staging (as in igemm_pipe_kernel) ----
   unsigned wo32[2];
 #pragma unroll
@@ -289,10 +262,50 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
 #pragma unroll
     for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // (tap offsets of the nine-tap loop: read before any copy is in flight -- a dynamically indexed short in the kernel
+  //  arguments is a vector load, and its wait would drain the LDS-DMA queue)
+  int tdh[9], tdw[9];
+  if constexpr (TAPS9) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      tdh[t] = __builtin_amdgcn_readfirstlane((int)p.dh[ph.tap0 + t]);
+      tdw[t] = __builtin_amdgcn_readfirstlane((int)p.dw[ph.tap0 + t]);
+    }
+  }
   // ---- prologue: patch of slice 0, weight stages 0 .. NS-2 ----
+  __builtin_amdgcn_sched_barrier(0);
   for (int j = 0; j < nmine; j++) patch_piece(0, j, 0);
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) issue_weights(s);
+  // (the fragment addresses are computed while those copies are in flight)
+  __builtin_amdgcn_sched_barrier(0);
+  // TAPS9: LDS byte offset (from the start of the shared array, patch slot 0; slot 1 is a constant further, which fits
+  // the DS instruction's 16-bit immediate) of this lane's chunk of fragment b at tap t
+  int qa[9][FP];
+  if constexpr (TAPS9) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int dh = tdh[t], dw = tdw[t];
+      const int qo = (dh - dh0) * PW + (dw - dw0);
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        int q = q0[b] + qo;
+        if constexpr (FOLD) {
+          const bool rh = dh > 0 ? f_rT[b] : (dh < 0 ? f_rB[b] : false);
+          const bool ch = dw > 0 ? f_hasL[b] : (dw < 0 ? f_hasR[b] : false);
+          const int vrow = dh > 0 ? vT0 : vB0;
+          if (rh) q = vrow + f_lx[b] + dw + 1;                                      // VT / VB cell of column v + dw
+          if (ch) {
+            const bool cl = dw > 0 ? f_cL[b] : f_cR[b];                             // this lane's pixel is the column
+            const int alt = rh ? vrow + PW + (dw > 0 ? 0 : 1) : (dw > 0 ? vL0 : vR0) + f_ly[b] + dh + 1;
+            q = cl ? alt : q;
+          }
+        }
+        qa[t][b] = (NS * STAGE + q * 4 + (fg ^ ((q >> 1) & 3))) * 16;
+      }
+    }
+  }
+
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NWL) : "memory");
   __syncthreads();              // sQ visible; every wave's patch rows and stage 0 have landed
   if constexpr (FOLD) {
