@@ -653,6 +653,267 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
   return 0;
 }
 
+// ---- One-pass backward of InstanceNorm / AdaIN (round 3): statistics + coefficients + apply in ONE launch, dy and x read ONCE --
+// The three-launch backward reads dy and x twice (statistics, then apply): 168 MB per K1 site where one pass needs 100 MB.  Here a
+// 512-thread workgroup owns a SLICE of an image -- 8192 consecutive 16-byte chunks of the NHWC plane (K1: 256 pixels x 256
+// channels), read as whole contiguous lines -- and keeps it IN REGISTERS (16 chunk pairs of x and dy = 128 VGPRs per thread,
+// 256 KiB per CU, every load in flight at once).  It reduces {sum g, sum g x} of its slice in a fixed order, publishes the partial
+// row, waits for the other slices of ITS IMAGE (arrive counter; the only inter-workgroup dependency, between workgroups with
+// neighbouring indices: workgroups are dispatched in index order, so the ones waited for are resident or next in line; a wait
+// that exceeds MT_OP_SPIN polls poisons the output with NaN instead of hanging), adds the image's rows in index order
+// (bit-reproducible), derives c1, c2, c3 exactly as norm_bwd_finalize_kernel does (slice 0 also writes the AdaIN parameter
+// gradients) and streams dx out of the registers.
+// Measured (tools/bench_norm.py, K1 [16, 256, 64, 64]): 31 us against 45 us for the three launches; inside the step 39 against
+// 50 us.  What the numbers taught: (1) one workgroup per (image, 16 channels) with the whole plane in registers needs no counter,
+// but a wave then reads 32-byte pieces at a 512-byte stride: 44 us, the L2 -> L1 path moves four times the bytes; (2) agent-scope
+// fences (__threadfence) around the exchange write back and invalidate the XCD's whole L2: 93 us -- the exchange uses
+// write-through atomic stores / loads and a vmcnt wait instead; (3) without the wait for the siblings (wrong results, diagnostic
+// build MT_OP_EXP_NOSPIN) the kernel takes 24 us: 7 us are the skew between the slices of an image plus the detection latency
+// of a far counter, and more, smaller slices cost more (4096-chunk slices: 48 us, 2048: 79 us).
+// sync = [2][N] counters, zero before the first launch; the last workgroup of an image to leave resets them (self-cleaning).
+#ifndef MT_OP_THREADS
+#define MT_OP_THREADS 512                   // threads per workgroup: 512 x 16 pairs (2 waves per SIMD, 256 registers: no spill)
+#endif
+#ifndef MT_OP_PAIRS
+#define MT_OP_PAIRS 16
+#endif
+#ifndef MT_OP_STORE_AUX
+#define MT_OP_STORE_AUX 2                   // cache policy of the dx stores (2 = nt, as mt_norm_bwd_apply's streaming stores)
+#endif
+constexpr int MT_OP_NT = MT_OP_THREADS;
+constexpr int MT_OP_SLICE = MT_OP_THREADS * MT_OP_PAIRS;   // 16-byte chunks of x (and of dy) per workgroup
+constexpr int MT_OP_SPIN = 1 << 22;          // polls before a waiting workgroup gives up and poisons its output (never a hang)
+template <int CCH, int NT, int P>
+__global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gb, float* __restrict__ dgb,
+                                                                u32x4* __restrict__ dx, float* __restrict__ part,
+                                                                unsigned* __restrict__ sync, int N, int HW, int C, int S,
+                                                                int mode, int act, float slope) {
+  constexpr int V = 8, NW = NT / 64;
+  static_assert(NT * P == MT_OP_SLICE && NT % CCH == 0 && P % 4 == 0, "slice geometry");
+  constexpr int cchunks = CCH;               // 16-byte channel chunks per pixel (power of two, 8..256)
+  constexpr int L = CCH < 64 ? CCH : 64;     // lanes of a wave that hold distinct chunks after the in-wave reduction
+  constexpr int Cp = CCH * V;
+  __shared__ float red[NW * L * 16];         // [wave][lane < L][{s1[8], s2[8]}]
+  __shared__ float tot[2 * Cp];
+  __shared__ float kf[3 * Cp];
+  __shared__ int ok_flag;
+
+  const int n = blockIdx.x / S, sl = blockIdx.x - n * S;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = tid & (cchunks - 1);         // NT % cchunks == 0: the same channel chunk for all pairs of a thread
+  const long co = (long)n * Cp + q * V;
+  // slice-relative buffer resources: one 32-bit lane offset, the pair stride (16 KiB) as the scalar offset
+  const long sbase = ((long)n * S + sl) * MT_OP_SLICE;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + sbase), 0, MT_OP_SLICE * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + sbase), 0, MT_OP_SLICE * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dx + sbase), 0, MT_OP_SLICE * 16, 0x00020000);
+  const unsigned voff = (unsigned)tid * 16u;
+  u32x4 xv[P], gv[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    xv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, j * (NT * 16), 0);
+    gv[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, voff, j * (NT * 16), 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);         // all 2P loads are issued before anything else
+  unsigned msk[P / 4];                       // act'(z) as one bit per element (z > 0): the forward scale / shift are dead after this
+#pragma unroll
+  for (int i = 0; i < P / 4; i++) msk[i] = 0u;
+  const float neg = act == MT_ACT_RELU ? 0.f : (act == MT_ACT_LRELU ? slope : 1.f);
+  // pair by pair in load order: the arithmetic of pair j runs while the later pairs are still in flight
+  {
+    float sc[V], sh[V], s1[V], s2[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) { sc[e] = scale[co + e]; sh[e] = shift[co + e]; s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      // (an IR-level fence: without it the optimiser computes the compare masks of all 16 pairs first and spills; sched_barrier
+      // only binds the machine scheduler)
+      asm volatile("" : "+v"(xv[j]), "+v"(gv[j]), "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]),
+                        "+v"(s1[6]), "+v"(s1[7]), "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]),
+                        "+v"(s2[6]), "+v"(s2[7]));
+      float f[V], g[V];
+      Elem<true>::unpack(xv[j], f);
+      Elem<true>::unpack(gv[j], g);
+      unsigned mb = 0u;
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        const bool pos = sc[e] * f[e] + sh[e] > 0.f;
+        mb |= (pos ? 1u : 0u) << e;
+        const float gg = g[e] * (pos ? 1.f : neg);
+        s1[e] += gg;
+        s2[e] += gg * f[e];
+      }
+      msk[j >> 2] |= mb << ((j & 3) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+#pragma unroll
+      for (int o = cchunks; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    }
+    if (lane < L) {
+      float* r = red + (wv * L + lane) * 16;
+#pragma unroll
+      for (int e = 0; e < V; e++) { r[e] = s1[e]; r[V + e] = s2[e]; }
+    }
+  }
+  __syncthreads();
+  // the slice's partial row [Cp][2] = {sum g, sum g x}: waves in index order.  Chunk cq sits in lane cq % 64 of the waves
+  // w = cq / 64 + k * (cchunks / 64) (cchunks <= 64: every wave)
+  float* const prow = part + ((long)n * S + sl) * Cp * 2;
+  {
+    constexpr int wstep = cchunks <= 64 ? 1 : cchunks >> 6;
+    for (int o = tid; o < Cp * 2; o += NT) {
+      const int c = o >> 1, k = o & 1, cq = c >> 3, e = c & 7;
+      float a = 0.f;
+      for (int w = cq >> 6; w < NW; w += wstep) a += red[(w * L + (cq & 63)) * 16 + k * V + e];
+      __hip_atomic_store(&prow[o], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the row went out as write-through (agent-scope) stores: waiting for their completion orders them before the arrive
+  // increment.  (NOT __threadfence(): an agent-scope release / acquire pair writes back and invalidates the XCD's whole L2 --
+  // measured 93 us per round of workgroups with the fences against a 20 us budget.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    int ok = 1;
+    if (S > 1) {
+      atomicAdd(&sync[n], 1u);
+      int spins = 0;
+#ifdef MT_OP_EXP_NOSPIN
+      while (false) {
+#else
+      while (__hip_atomic_load(&sync[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+#endif
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > MT_OP_SPIN) { ok = 0; break; }
+      }
+    }
+    ok_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = ok_flag != 0;
+  // the image's totals: its S rows in index order (every slice adds them the same way: identical coefficients everywhere)
+  {
+    const float* irow = part + (long)n * S * Cp * 2;
+    for (int o = tid; o < Cp * 2; o += NT) {
+      float a = 0.f;
+#ifdef MT_OP_EXP_NOROWS
+      for (int s0 = 0; s0 < 1; s0 += 16) {
+#else
+      for (int s0 = 0; s0 < S; s0 += 16) {     // sixteen rows in flight (a dependent chain of far loads would cost ~1 us each)
+#endif
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          v[i] = s0 + i < S ? __hip_atomic_load(&irow[(long)(s0 + i) * Cp * 2 + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) a += v[i];
+      }
+      tot[o] = ok ? a : __builtin_nanf("");
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < Cp; c += NT) {
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (c < C) {
+      const long i = (long)n * Cp + c;
+      const float m = mean[i], r = rstd[i];
+      const float S1 = tot[2 * c], S2 = tot[2 * c + 1];
+      const float gxh = r * (S2 - m * S1);
+      float a = 1.f;
+      if (mode == MT_NORM_ADAIN) {
+        a = 1.f + gb[(long)n * 2 * C + c];
+        if (sl == 0) {
+          dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
+          dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
+        }
+      }
+      const float hw = (float)HW;
+      k1 = r * a;
+      k3 = -r * a * r * gxh / hw;
+      k2 = -r * a * S1 / hw - k3 * m;
+    }
+    kf[c] = k1; kf[Cp + c] = k2; kf[2 * Cp + c] = k3;
+  }
+  __syncthreads();
+  // (opaque to the optimiser: it would otherwise keep the unpacked floats of the statistics phase alive for this one, 3x the
+  // payload, and the 128 compare masks in SGPRs)
+#pragma unroll
+  for (int j = 0; j < P; j++) asm volatile("" : "+v"(xv[j]), "+v"(gv[j]));
+#pragma unroll
+  for (int i = 0; i < P / 4; i++) asm volatile("" : "+v"(msk[i]));
+  // dx pair by pair, each stored as soon as it is complete (the stores drain under the arithmetic of the later pairs)
+  float k1[V], k2[V], k3[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) { k1[e] = kf[q * V + e]; k2[e] = kf[Cp + q * V + e]; k3[e] = kf[2 * Cp + q * V + e]; }
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    asm volatile("" : "+v"(xv[j]), "+v"(gv[j]) : : "memory");     // pair j starts after pair j - 1 is stored
+    float f[V], g[V];
+    Elem<true>::unpack(xv[j], f);
+    Elem<true>::unpack(gv[j], g);
+    const unsigned mb = msk[j >> 2] >> ((j & 3) * 8);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float gg = g[e] * (((mb >> e) & 1u) ? 1.f : neg);
+      f[e] = k1[e] * gg + k2[e] + k3[e] * f[e];
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(Elem<true>::pack(f), rd, voff, j * (NT * 16), MT_OP_STORE_AUX);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (S > 1 && tid == 0) {                     // leave (off the critical path): the last one out clears the image's counters
+    const unsigned t = atomicAdd(&sync[N + n], 1u);
+    if (t == (unsigned)S - 1) {
+      __hip_atomic_store(&sync[n], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[N + n], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// Which problems the one-pass kernel takes: bf16, InstanceNorm / AdaIN, a power-of-two number of 16-byte channel chunks (64..2048
+// channels), image planes that are whole 8192-chunk slices, at least half a round of workgroups.
+// *slices = workgroups per image (the part workspace is [N][slices][Cp][2] floats, sync [2][N] zeroed counters).
+extern "C" int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int* slices) {
+  if (slices) *slices = 0;
+  if (dtype != MT_BF16 || !(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN) || N <= 0 || HW <= 0 || Cp < 8 || Cp % 8) return 0;
+  const int cchunks = Cp / 8;
+  if ((cchunks & (cchunks - 1)) != 0 || cchunks < 8 || cchunks > 256) return 0;
+  if (!(act == MT_ACT_NONE || act == MT_ACT_RELU || act == MT_ACT_LRELU)) return 0;
+  const long chunks = (long)HW * cchunks;
+  if (chunks % MT_OP_SLICE != 0) return 0;
+  const long S = chunks / MT_OP_SLICE;
+  if (S > 1024 || (long)N * S < 128 || (long)N * S > 0x7fffffffL) return 0;
+  if (slices) *slices = (int)S;
+  return 1;
+}
+extern "C" int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
+                                   const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,
+                                   unsigned* sync, int N, int HW, int C, int Cp, int act, float slope, mt_stream_t st) {
+  int S = 0;
+  MT_CHECK(mt_norm_bwd_onepass_ok(dtype, mode, N, HW, Cp, act, &S), "norm_bwd_onepass: unsupported problem (dtype %d mode %d HW %d Cp %d act %d)",
+           dtype, mode, HW, Cp, act);
+  MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_onepass: adain needs gb/dgb");
+  MT_CHECK(part != nullptr && sync != nullptr, "norm_bwd_onepass: needs the part / sync workspaces");
+  MT_CHECK(C <= Cp && C > Cp - 8, "norm_bwd_onepass: C %d does not pad to Cp %d", C, Cp);
+  hipStream_t s = (hipStream_t)st;
+  const int cchunks = Cp / 8;
+#define MT_ONEPASS(CC)                                                                                                       \
+  case CC:                                                                                                                   \
+    hipLaunchKernelGGL((norm_bwd_onepass_kernel<CC, MT_OP_NT, MT_OP_PAIRS>), dim3(N * S), dim3(MT_OP_NT), 0, s, (const u32x4*)dy, (const u32x4*)x, scale, \
+                       shift, mean, rstd, gb, dgb, (u32x4*)dx, part, sync, N, HW, C, S, mode, act, slope);                  \
+    break
+  switch (cchunks) {
+    MT_ONEPASS(8); MT_ONEPASS(16); MT_ONEPASS(32); MT_ONEPASS(64); MT_ONEPASS(128); MT_ONEPASS(256);
+    default: MT_CHECK(false, "norm_bwd_onepass: %d channel chunks", cchunks);
+  }
+#undef MT_ONEPASS
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- BatchNorm2d (--enc_norm / --dec_norm / --dis_norm batch; functions.py:14-15: affine, running statistics) ---------------
 // Same four passes as the other norms: the per-(image, channel) sums are pooled over the batch here, the per-(n, c)
 // coefficient arrays are filled with the per-channel values so the elementwise kernels are shared.

@@ -453,6 +453,29 @@ def set_stats_link(on):
     _STATS_LINK_ON[0] = bool(on)
 
 
+# One-pass backward of InstanceNorm / AdaIN (mt_norm_bwd_onepass: statistics + coefficients + apply in one launch, dy and x read
+# once; planes of 1024 / 2048 / 4096 pixels in bf16).  MT_NORM_ONEPASS=0 / set_norm_onepass(False): the three-launch backward.
+_NORM_ONEPASS_ON = [os.environ.get("MT_NORM_ONEPASS", "1") != "0"]
+
+
+def set_norm_onepass(on):
+    _NORM_ONEPASS_ON[0] = bool(on)
+
+
+_ONEPASS_SYNC = {}
+
+
+def _onepass_sync(dev, n):
+    """Per-(device, stream) arrive / leave counters of mt_norm_bwd_onepass ([2][N] uint32, zero; the kernel leaves them zero, so
+    the buffer is allocated once -- a captured graph keeps using the same address -- and grown only for a larger batch)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ONEPASS_SYNC.get(key)
+    if buf is None or buf.numel() < 2 * n:
+        buf = torch.zeros(2 * max(n, 64), dtype=torch.int32, device=dev)
+        _ONEPASS_SYNC[key] = buf
+    return buf
+
+
 def stats_link_of(t):
     """the StatsLink a normalisation hung on its output tensor, if any (and fused statistics are allowed at all)"""
     return None if (_DETERMINISTIC[0] or not _STATS_LINK_ON[0]) else getattr(t, "_mt_stats_link", None)
@@ -894,7 +917,26 @@ class _Norm(torch.autograd.Function):
         dev = x.device
         mt = _mt(x.dtype)
         sl = ctx.slink
-        if sl is not None and sl.sums is not None and tuple(sl.sums.shape) == (N, Cp, 2):
+        linked = sl is not None and sl.sums is not None and tuple(sl.sums.shape) == (N, Cp, 2)
+        slices = C.c_int(0)
+        if (_NORM_ONEPASS_ON[0] and not linked and ctx.needs_input_grad[0]
+                and lib.mt_norm_bwd_onepass_ok(mt, mode, N, HW, Cp, act, C.byref(slices))):
+            if sl is not None:
+                sl.sums = None
+            dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
+            dx = new_act(N, Cc, H, W, x.dtype, dev)
+            part = torch.empty((N, slices.value, Cp, 2), dtype=torch.float32, device=dev)
+            with _hbm("norm_bwd_onepass", N * HW * Cp * x.element_size() * 3):
+                L.check(lib.mt_norm_bwd_onepass(mt, mode, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]),
+                                                _ptr(coef[3]), _ptr(gbc), _ptr(dgb), _ptr(dx), _ptr(part),
+                                                _ptr(_onepass_sync(dev, N)), N, HW, Cc, Cp, act, slope, _stream()),
+                        "mt_norm_bwd_onepass")
+            dres = dy if ctx.needs_input_grad[4] else None
+            link = ctx.cfg[5] if len(ctx.cfg) > 5 else None
+            if link is not None and dres is not None:
+                link.g, dres = dres, None
+            return dx, dgb, None, None, dres, None, None
+        if linked:
             # the kernel that produced dy took the sums in its epilogue (StatsLink): one partial row per image
             sums2, nparts = sl.sums, 1
             sl.sums = None
