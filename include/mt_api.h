@@ -143,6 +143,17 @@ size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
  * the parameter's .grad and skip a separate accumulation pass). */
 int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
+/* Grouped weight gradient: G (2..4) convolutions OF THE SAME DESCRIPTOR in one launch (reference: the weight gradients
+ * autograd computes one by one for nn.Conv2d, blocks.py:131-132,150-151 -- they are leaves of the backward pass, so their
+ * order is free).  The 256x256 weight-gradient kernel splits the pixel reduction to fill the chip and writes one fp32 slab
+ * of the whole gradient per split (28 for the dominant layer); G problems share the chip with 28 / G splits each.
+ * mt_conv_bwd_weight_group_max: the largest G this descriptor supports (1 = use mt_conv_bwd_weight); x, dy, dw: tables of
+ * G device pointers; ws >= mt_conv_bwd_weight_group_ws_bytes(d, G); no bias gradient (take it from mt_conv_bwd_weight_partial
+ * or mt_act_bwd_bias).  Results equal mt_conv_bwd_weight's up to the fp32 summation order over the pixels. */
+int mt_conv_bwd_weight_group_max(const mt_conv_desc* d);
+size_t mt_conv_bwd_weight_group_ws_bytes(const mt_conv_desc* d, int G);
+int mt_conv_bwd_weight_group(const mt_conv_desc* d, int G, const void* const* x, const void* const* dy, float* const* dw,
+                             void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
 /* The same in two halves (mt_conv_bwd_weight = partial + finish on one stream): `partial` runs the bias gradient (if
  * dbias != NULL) and the split GEMM into fp32 slabs in ws and reports their number; `finish` is the streaming sum of
  * the slabs into dw.  A caller may issue `finish` on ANOTHER stream (after an event recorded behind `partial`) so that

@@ -64,6 +64,9 @@ SIGNATURES = {
     "mt_conv_bwd_data_ex": (_i, [_dp, _p, _p, _p, _p, C.POINTER(BwdStats), C.POINTER(C.c_int), _p, _z, _p]),
     "mt_conv_bwd_weight_ws_bytes": (_z, [_dp]),
     "mt_conv_bwd_weight": (_i, [_dp, _p, _p, _p, _p, _p, _z, _i, _p]),
+    "mt_conv_bwd_weight_group_max": (_i, [_dp]),
+    "mt_conv_bwd_weight_group_ws_bytes": (_z, [_dp, _i]),
+    "mt_conv_bwd_weight_group": (_i, [_dp, _i, _p, _p, _p, _p, _z, _i, _p]),
     "mt_conv_bwd_weight_partial": (_i, [_dp, _p, _p, _p, _p, _z, _i, _i, C.POINTER(C.c_int), _p]),
     "mt_conv_bwd_weight_finish": (_i, [_dp, _p, _i, _p, _i, _p]),
     "mt_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

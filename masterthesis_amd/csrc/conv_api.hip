@@ -669,6 +669,35 @@ extern "C" size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d) {
   return slabs > bias ? slabs : bias;
 }
 
+// geometry of the weight-gradient GEMM of one convolution (everything but the pixel split and the slab pointer)
+static void wgrad_params(const mt_conv_desc* d, const void* x, const void* dy, WgradParams* pp) {
+  WgradParams& p = *pp;
+  memset(&p, 0, sizeof(p));
+  int Ho, Wo;
+  mt_conv_out_hw(d, &Ho, &Wo);
+  const int sz = esz(d->dtype), V = vec(d->dtype);
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  p.N = d->N; p.is = d->stride; p.ntaps = K2;
+  for (int a = 0; a < d->kh; a++)
+    for (int b = 0; b < d->kw; b++) {
+      const int t = a * d->kw + b;
+      p.dh[t] = (short)(a - d->pad); p.dw[t] = (short)(b - d->pad);
+    }
+  if (!d->transposed) {
+    // dW[co][kh][kw][ci] = sum dy[n,ho,wo,co] * x[n, pad(ho*s-p+kh), pad(wo*s-p+kw), ci]
+    p.a = (const char*)dy; p.Cab = Cop * sz; p.CaRows = Cop; p.Ho = Ho; p.Wo = Wo;
+    p.b = (const char*)x; p.Hi = d->H; p.Wi = d->W; p.Cbb = Cip * sz; p.cpc = Cip / V;
+    p.pad_mode = d->pad_mode;
+  } else {
+    // dW[ci][co][kh][kw] = sum x[n,hi,wi,ci] * dy[n, hi*s-p+kh, wi*s-p+kw, co]  (zero outside)
+    p.a = (const char*)x; p.Cab = Cip * sz; p.CaRows = Cip; p.Ho = d->H; p.Wo = d->W;
+    p.b = (const char*)dy; p.Hi = Ho; p.Wi = Wo; p.Cbb = Cop * sz; p.cpc = Cop / V;
+    p.pad_mode = MT_PAD_ZERO;
+  }
+  p.M = d->N * p.Ho * p.Wo;
+  p.nchunks = p.ntaps * p.cpc;
+}
+
 // The weight gradient in two halves, so that a caller may run the second one (a pure streaming reduction of the
 // split slabs) on another stream beside the next layer's GEMMs:
 //   partial: [bias gradient, if asked for] then the split GEMM -> fp32 slabs in ws; *nslabs = how many
@@ -699,8 +728,7 @@ extern "C" int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, 
   *nslabs = 0;
   int Ho, Wo;
   mt_conv_out_hw(d, &Ho, &Wo);
-  const int sz = esz(d->dtype), V = vec(d->dtype);
-  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
+  const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co);
   // the bias gradient first: its partials use the workspace before the slabs do (stream order)
   if (dbias != nullptr) {
     const long npix = mt_pointwise_small(d) ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
@@ -720,27 +748,8 @@ extern "C" int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, 
     return 0;
   }
   WgradParams p;
-  memset(&p, 0, sizeof(p));
+  wgrad_params(d, x, dy, &p);
   p.out = (float*)ws;
-  p.N = d->N; p.is = d->stride; p.ntaps = K2;
-  for (int a = 0; a < d->kh; a++)
-    for (int b = 0; b < d->kw; b++) {
-      const int t = a * d->kw + b;
-      p.dh[t] = (short)(a - d->pad); p.dw[t] = (short)(b - d->pad);
-    }
-  if (!d->transposed) {
-    // dW[co][kh][kw][ci] = sum dy[n,ho,wo,co] * x[n, pad(ho*s-p+kh), pad(wo*s-p+kw), ci]
-    p.a = (const char*)dy; p.Cab = Cop * sz; p.CaRows = Cop; p.Ho = Ho; p.Wo = Wo;
-    p.b = (const char*)x; p.Hi = d->H; p.Wi = d->W; p.Cbb = Cip * sz; p.cpc = Cip / V;
-    p.pad_mode = d->pad_mode;
-  } else {
-    // dW[ci][co][kh][kw] = sum x[n,hi,wi,ci] * dy[n, hi*s-p+kh, wi*s-p+kw, co]  (zero outside)
-    p.a = (const char*)x; p.Cab = Cip * sz; p.CaRows = Cip; p.Ho = d->H; p.Wo = d->W;
-    p.b = (const char*)dy; p.Hi = Ho; p.Wi = Wo; p.Cbb = Cop * sz; p.cpc = Cop / V;
-    p.pad_mode = MT_PAD_ZERO;
-  }
-  p.M = d->N * p.Ho * p.Wo;
-  p.nchunks = p.ntaps * p.cpc;
   int nsplit;
   bool pipe;
   wgrad_split(d, p.M, &nsplit, &p.mchunk, &pipe);
@@ -768,4 +777,69 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   const int rc = mt_conv_bwd_weight_partial(d, x, dy, dbias, ws, ws_bytes, accumulate, dw != nullptr, &nslabs, st);
   if (rc) return rc;
   return dw != nullptr ? mt_conv_bwd_weight_finish(d, ws, nslabs, dw, accumulate, st) : 0;
+}
+
+// ---- grouped weight gradient (round 3) ----------------------------------------------------------------------------------
+// The 256x256 ping-pong weight gradient splits the pixel reduction so that (tiles x splits) fills the 256 CUs: the dominant
+// layer (9 tiles) runs 28 splits, i.e. it writes 28 fp32 slabs of the whole gradient (66 MB) and the slab sum reads them
+// back -- 36 of its 93 us at N = 16.  Weight gradients are leaves of the backward pass (nothing waits for them before the
+// optimizer step), so G problems OF THE SAME GEOMETRY can share one launch: G x 9 tiles x 28 / G splits, a quarter of the slab
+// bytes per problem at G = 4.  The longer splits need the 16-bit pixel-delta table of wgrad_pipe_kernel<COMPACT>.
+static bool wgrad_group_split(const mt_conv_desc* d, int G, int* nsplit, int* mchunk) {
+  if (G < 2 || G > MT_WGRAD_MAX_GROUP || mt_stem_wgrad_ok(d) || mt_pointwise_small(d)) return false;
+  WgradParams p;
+  wgrad_params(d, nullptr, nullptr, &p);
+  const int V = vec(d->dtype), sz = esz(d->dtype);
+  const long ab = (long)p.M * p.Cab, bb = (long)p.N * p.Hi * p.Wi * p.Cbb;
+  if (!mt_wgrad_pipe_ok(d->dtype, p.CaRows, p.cpc, ab, bb) || !mt_wgrad_pipe_compact_ok(p)) return false;
+  (void)sz;
+  const int tiles = (p.CaRows / 256) * (p.nchunks * V / 256);
+  const int ns = 256 / (tiles * G);
+  if (ns < 1 || p.M / ns < 512 || ns * tiles * G < 200) return false;
+  const int mc = cdiv(cdiv(p.M, ns), 32) * 32;
+  if (mc > mt_wgrad_pipe_max_chunk_compact()) return false;
+  *mchunk = mc;
+  *nsplit = cdiv(p.M, mc);
+  return true;
+}
+extern "C" int mt_conv_bwd_weight_group_max(const mt_conv_desc* d) {
+  if (check_desc(d)) return 1;
+  int ns, mc;
+  for (int G = MT_WGRAD_MAX_GROUP; G >= 2; G--)
+    if (wgrad_group_split(d, G, &ns, &mc)) return G;
+  return 1;
+}
+extern "C" size_t mt_conv_bwd_weight_group_ws_bytes(const mt_conv_desc* d, int G) {
+  int ns, mc;
+  if (check_desc(d) || !wgrad_group_split(d, G, &ns, &mc)) return 0;
+  return (size_t)G * ns * mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+}
+extern "C" int mt_conv_bwd_weight_group(const mt_conv_desc* d, int G, const void* const* x, const void* const* dy,
+                                        float* const* dw, void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  hipStream_t s = (hipStream_t)st;
+  int nsplit, mchunk;
+  MT_CHECK(wgrad_group_split(d, G, &nsplit, &mchunk), "conv_bwd_weight_group: %d problems of this geometry cannot share a launch", G);
+  MT_CHECK(x != nullptr && dy != nullptr && dw != nullptr, "conv_bwd_weight_group: NULL pointer table");
+  const size_t need = mt_conv_bwd_weight_group_ws_bytes(d, G);
+  MT_CHECK(ws != nullptr && ws_bytes >= need, "conv_bwd_weight_group: workspace too small");
+  WgradParams p;
+  wgrad_params(d, x[0], dy[0], &p);
+  const long slab = (long)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw;
+  p.ngroup = G;
+  for (int g = 0; g < G; g++) {
+    MT_CHECK(x[g] != nullptr && dy[g] != nullptr && dw[g] != nullptr, "conv_bwd_weight_group: NULL operand %d", g);
+    p.ga[g] = (const char*)(d->transposed ? x[g] : dy[g]);
+    p.gb[g] = (const char*)(d->transposed ? dy[g] : x[g]);
+    p.gout[g] = (float*)ws + (size_t)g * nsplit * slab;
+  }
+  p.out = p.gout[0];
+  p.mchunk = mchunk;
+  p.ntiles = -1;
+  if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
+  PackParams u;
+  bwd_weight_unpack_params(d, &u);
+  for (int g = 0; g < G; g++)
+    if (mt_launch_unpack(p.gout[g], dw[g], u, nsplit, slab, accumulate, s)) return 2;
+  return 0;
 }

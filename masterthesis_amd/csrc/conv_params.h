@@ -71,6 +71,7 @@ struct IgemmParams {
   short dw[MT_MAX_TAPS];
 };
 
+#define MT_WGRAD_MAX_GROUP 4
 struct WgradParams {
   const char* a;   // pixel-major [M][Cab bytes]: its channels become output rows
   const char* b;   // gathered NHWC [N][Hi][Wi][Cbb bytes]: (tap, channel) become output columns
@@ -87,6 +88,12 @@ struct WgradParams {
   int ntiles;      // output tiles (128x128) per split; grid = ntiles * nsplit blocks
   short dh[MT_MAX_TAPS];
   short dw[MT_MAX_TAPS];
+  // grouped launch (wgrad_pipe_kernel only): ngroup > 1 problems of this geometry in one grid, blocks = ngroup * ntiles * nsplit;
+  // problem g reads ga[g] / gb[g] and writes its nsplit slabs at gout[g] (a, b, out unused)
+  int ngroup;
+  const char* ga[MT_WGRAD_MAX_GROUP];
+  const char* gb[MT_WGRAD_MAX_GROUP];
+  float* gout[MT_WGRAD_MAX_GROUP];
 };
 
 struct PackParams {
@@ -111,6 +118,9 @@ int mt_launch_wgrad(int dtype, const WgradParams& p, int nsplit, hipStream_t s);
 // 256x256 ping-pong variant (wgrad_pipe_kernel.hip)
 bool mt_wgrad_pipe_ok(int dtype, int CaRows, int cpc, long a_bytes, long b_bytes);
 int mt_wgrad_pipe_max_chunk();
+// ... with 16-bit pixel deltas in the per-block table (stride-1 problems whose two pixel grids coincide): twice the pixels per split
+bool mt_wgrad_pipe_compact_ok(const WgradParams& p);
+int mt_wgrad_pipe_max_chunk_compact();
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
 // one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch

@@ -34,7 +34,10 @@ __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
   return r;
 }
 
-template <bool REFLECT, int NS>
+// COMPACT (grouped launches, where a split is longer than the 32-bit table holds): the table holds 16-bit PIXEL deltas
+// (gathered pixel - own pixel; stride 1 and coinciding pixel grids, so |delta| <= pad * (W + 1)) and the byte offset is formed
+// in the memory phase (one multiply-add and a select per copy).
+template <bool REFLECT, int NS, bool COMPACT>
 __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
   constexpr int KP = 32;                    // pixels per k-step = K of one v_mfma_f32_16x16x32_bf16
   constexpr int ROWB = 512;                 // LDS row: 256 bf16 of one pixel
@@ -54,7 +57,14 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
 
   const int nAT = p.CaRows >> 8;
   const int vid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = vid / p.ntiles, tile = vid - split * p.ntiles;
+  // (split, problem of the group, tile): all tiles of all problems of a pixel split on one XCD
+  const int ngrp = p.ngroup > 1 ? p.ngroup : 1;
+  const int ntt = p.ntiles * ngrp;
+  const int split = vid / ntt, rest = vid - split * ntt;
+  const int gi = rest / p.ntiles, tile = rest - gi * p.ntiles;
+  const char* const pa = p.ngroup > 1 ? p.ga[gi] : p.a;
+  const char* const pb = p.ngroup > 1 ? p.gb[gi] : p.b;
+  float* const pout = p.ngroup > 1 ? p.gout[gi] : p.out;
   const int at = tile % nAT, bt = tile / nAT;
   const int mbeg = split * p.mchunk;
   const int mend = min(p.M, mbeg + p.mchunk);   // host guarantees mbeg < mend
@@ -86,9 +96,17 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
         } else {
           ok = ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
         }
-        if (ok) off = (unsigned)((n * p.Hi + hi) * p.Wi + wi) * (unsigned)p.Cbb + bch_bytes;
+        if constexpr (COMPACT) {
+          if (ok) off = (unsigned)(((n * p.Hi + hi) * p.Wi + wi) - m) & 0xffffu;
+          else off = 0x8000u;
+        } else {
+          if (ok) off = (unsigned)((n * p.Hi + hi) * p.Wi + wi) * (unsigned)p.Cbb + bch_bytes;
+        }
+      } else if constexpr (COMPACT) {
+        off = 0x8000u;
       }
-      sT[i] = off;
+      if constexpr (COMPACT) reinterpret_cast<unsigned short*>(sT)[i] = (unsigned short)off;
+      else sT[i] = off;
     }
   }
 
@@ -107,8 +125,8 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
     mrow[i] = mbeg + srow[i];
     ao32[i] = (unsigned)mrow[i] * (unsigned)p.Cab + (unsigned)at * 512u + cc16[i];
   }
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, p.b_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   char* const lds0 = reinterpret_cast<char*>(&smem[0]);
   const unsigned a_step = (unsigned)KP * (unsigned)p.Cab;
@@ -129,14 +147,28 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
   };
   int tpos = 0;                 // table row block of the NEXT stage to issue
   unsigned tq[2];
+  const short* const sT16 = reinterpret_cast<const short*>(sT);
+  const unsigned cbb = (unsigned)p.Cbb;      // (a local: a lambda that touches p by reference sends the whole parameter block to scratch)
+  auto lookup = [&](int i) -> unsigned {
+    if constexpr (COMPACT) return (unsigned)(int)sT16[tpos + srow[i]];      // sign-extended pixel delta, 0xffff8000 = no pixel
+    else return sT[tpos + srow[i]];
+  };
+  auto offset_of = [&](int i, unsigned t) -> unsigned {
+    if constexpr (COMPACT) {
+      const unsigned o = (unsigned)(mbeg + tpos + srow[i] + (int)t) * cbb + bch_bytes + cc16[i];
+      return t == 0xffff8000u ? OOB : o;
+    } else {
+      return t + cc16[i];
+    }
+  };
   auto next_lookup = [&]() {
     tpos += KP;
 #pragma unroll
-    for (int i = 0; i < 2; i++) tq[i] = sT[tpos + srow[i]];
+    for (int i = 0; i < 2; i++) tq[i] = lookup(i);
   };
-  auto next_offsets = [&]() {
+  auto next_offsets = [&]() {      // (always called with tpos still at the stage next_lookup read)
 #pragma unroll
-    for (int i = 0; i < 2; i++) xo32[i] = tq[i] + cc16[i];
+    for (int i = 0; i < 2; i++) xo32[i] = offset_of(i, tq[i]);
   };
 
   f32x4 acc[8][4];
@@ -147,7 +179,7 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
 
   __syncthreads();   // offset table visible
 #pragma unroll
-  for (int i = 0; i < 2; i++) xo32[i] = sT[srow[i]] + cc16[i];
+  for (int i = 0; i < 2; i++) xo32[i] = offset_of(i, lookup(i));
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) {
     issue_stage(s);
@@ -230,7 +262,7 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
   // ---- epilogue: this split's fp32 slab [CaRows][ncols] ----
   const int fr = lane & 15, fg = lane >> 4;
   const int ncols = p.nchunks * 8;
-  float* slab = p.out + (size_t)split * p.CaRows * ncols;
+  float* slab = pout + (size_t)split * p.CaRows * ncols;
 #pragma unroll
   for (int a = 0; a < 8; a++) {
     const int ca = at * 256 + waI * 128 + a * 16 + fr;
@@ -247,12 +279,27 @@ bool mt_wgrad_pipe_ok(int dtype, int CaRows, int cpc, long a_bytes, long b_bytes
   return dtype == MT_BF16 && CaRows % 256 == 0 && (cpc * 8) % 256 == 0 && a_bytes < 0x7f000000L && b_bytes < 0x7f000000L;
 }
 int mt_wgrad_pipe_max_chunk() { return MT_WGP_MAXM - 6 * 32; }
+int mt_wgrad_pipe_max_chunk_compact() { return 2 * MT_WGP_MAXM - 6 * 32; }
+bool mt_wgrad_pipe_compact_ok(const WgradParams& p) {
+  return p.is == 1 && p.Hi == p.Ho && p.Wi == p.Wo && (long)p.Wi * 4 + 4 < 32000;
+}
 
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s) {
-  MT_CHECK(p.mchunk <= mt_wgrad_pipe_max_chunk(), "wgrad_pipe: pixel chunk %d exceeds the offset table", p.mchunk);
-  dim3 grid(p.ntiles * nsplit);
-  if (p.pad_mode == MT_PAD_REFLECT) hipLaunchKernelGGL((wgrad_pipe_kernel<true, 4>), grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((wgrad_pipe_kernel<false, 4>), grid, dim3(512), 0, s, p);
+  const int ngrp = p.ngroup > 1 ? p.ngroup : 1;
+  MT_CHECK(ngrp <= MT_WGRAD_MAX_GROUP, "wgrad_pipe: group of %d", ngrp);
+  const bool compact = p.mchunk > mt_wgrad_pipe_max_chunk();
+  if (compact)
+    MT_CHECK(mt_wgrad_pipe_compact_ok(p) && p.mchunk <= mt_wgrad_pipe_max_chunk_compact(),
+             "wgrad_pipe: pixel chunk %d exceeds the offset table", p.mchunk);
+  dim3 grid(p.ntiles * nsplit * ngrp);
+  const bool refl = p.pad_mode == MT_PAD_REFLECT;
+  if (compact) {
+    if (refl) hipLaunchKernelGGL((wgrad_pipe_kernel<true, 4, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_pipe_kernel<false, 4, true>), grid, dim3(512), 0, s, p);
+  } else {
+    if (refl) hipLaunchKernelGGL((wgrad_pipe_kernel<true, 4, false>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_pipe_kernel<false, 4, false>), grid, dim3(512), 0, s, p);
+  }
   MT_LAUNCH_CHECK();
   return 0;
 }

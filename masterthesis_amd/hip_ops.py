@@ -613,6 +613,8 @@ class _Conv(torch.autograd.Function):
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
+            if gw is not None and not need_b and _wgrad_group_defer(ctx, desc, x, dy, gw):
+                return dx, None, db, None          # launched with its group (or at the end of this backward pass)
             if gw is not None and (gbw is not None or not need_b):
                 # accumulate in place; autograd gets None for both
                 with _oplog("wgrad", desc, (int(need_b),)):
@@ -627,6 +629,88 @@ class _Conv(torch.autograd.Function):
                                                    _ptr(ws), nws, 0, _stream()), "mt_conv_bwd_weight")
         _grad_use_done(ctx)
         return dx, dw, db, None
+
+
+# ---- grouped weight gradients ------------------------------------------------------------------------------------------
+# Weight gradients are leaves of the backward pass: nothing in it waits for them.  The 256x256 weight-gradient kernel splits the
+# pixel reduction 28 ways to fill the chip for ONE problem of the dominant layer (66 MB of fp32 slabs written and read back); up
+# to four problems of the same descriptor share one launch instead (mt_conv_bwd_weight_group: 28 / G splits each).  A problem
+# waits in a per-descriptor queue until its group is full; what is left when the backward pass ends goes out from an autograd
+# engine callback (queued with the first deferred problem), so param.grad is complete when backward() returns.
+# MT_WGRAD_GROUP=0 / set_wgrad_group(False): every weight gradient is launched where autograd reaches it.
+_WGRAD_GROUP_ON = [os.environ.get("MT_WGRAD_GROUP", "1") != "0"]
+_WGRAD_QUEUE = {"pending": {}, "armed": None, "gmax": {}}      # armed: id of the autograd graph task whose callback will flush
+
+
+def set_wgrad_group(on):
+    flush_wgrad_groups()
+    _WGRAD_GROUP_ON[0] = bool(on)
+
+
+def _desc_key(desc):
+    return bytes(desc)
+
+
+def _wgrad_group_defer(ctx, desc, x, dy, gw):
+    if not _WGRAD_GROUP_ON[0]:
+        return False
+    key = _desc_key(desc)
+    gmax = _WGRAD_QUEUE["gmax"].get(key)
+    if gmax is None:
+        gmax = int(L.load().mt_conv_bwd_weight_group_max(C.byref(desc)))
+        _WGRAD_QUEUE["gmax"][key] = gmax
+    if gmax < 2:
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False                                 # not inside an engine run (backward called by hand): nothing would flush
+    if _WGRAD_QUEUE["armed"] != task:
+        if _WGRAD_QUEUE["pending"]:                  # left over from a backward pass that died before its callback ran
+            flush_wgrad_groups()
+        _WGRAD_QUEUE["armed"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_groups)
+    q = _WGRAD_QUEUE["pending"].setdefault(key, [])
+    q.append((ctx, desc, x, dy, gw))
+    if len(q) >= gmax:
+        _wgrad_group_launch(_WGRAD_QUEUE["pending"].pop(key))
+    return True
+
+
+def _wgrad_group_launch(items):
+    lib = L.load()
+    desc = items[0][1]
+    G = len(items)
+    dev = items[0][2].device
+    if G == 1:
+        ctx, desc, x, dy, gw = items[0]
+        nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
+        ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+        with _oplog("wgrad", desc, (0,)):
+            L.check(lib.mt_conv_bwd_weight(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gw), None, _ptr(ws), nws, 1, _stream()),
+                    "mt_conv_bwd_weight")
+    else:
+        nws = int(lib.mt_conv_bwd_weight_group_ws_bytes(C.byref(desc), G))
+        if nws == 0:                         # this group size does not fit one launch (e.g. three of four): split it
+            _wgrad_group_launch(items[:G // 2])
+            _wgrad_group_launch(items[G // 2:])
+            return
+        ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+        xs = (C.c_void_p * G)(*[it[2].data_ptr() for it in items])
+        dys = (C.c_void_p * G)(*[it[3].data_ptr() for it in items])
+        gws = (C.c_void_p * G)(*[it[4].data_ptr() for it in items])
+        with _oplog("wgrad", desc, (0, G)):
+            L.check(lib.mt_conv_bwd_weight_group(C.byref(desc), G, xs, dys, gws, _ptr(ws), nws, 1, _stream()),
+                    "mt_conv_bwd_weight_group")
+    for it in items:
+        _grad_use_done(it[0])
+
+
+def flush_wgrad_groups():
+    """launch every deferred weight gradient (autograd engine callback at the end of a backward pass; also safe to call by hand)"""
+    _WGRAD_QUEUE["armed"] = None
+    pend, _WGRAD_QUEUE["pending"] = _WGRAD_QUEUE["pending"], {}
+    for items in pend.values():
+        _wgrad_group_launch(items)
 
 
 def _grad_use_done(ctx):

@@ -54,8 +54,10 @@ def main():
     ev = ops.oplog_stop()
     agg = collections.OrderedDict()
     for kind, d, ms in ev:
-        e = agg.setdefault((kind, d), [0, 0.0])
-        e[0] += 1
+        # (a grouped weight-gradient launch carries its group size behind the descriptor: G calls of that layer)
+        g = d[16] if kind == "wgrad" and len(d) > 16 else 1
+        e = agg.setdefault((kind, d[:15]), [0, 0.0])
+        e[0] += g
         e[1] += ms
     rows = []
     for (kind, d), (n, ms) in agg.items():
