@@ -162,6 +162,12 @@ int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, const void*
                                size_t ws_bytes, int accumulate, int want_dw, int* nslabs, mt_stream_t s);
 int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate,
                               mt_stream_t s);
+/* Size of one slab of mt_conv_bwd_weight_partial if the slabs have the generic form (it depends on the weight's shape only), else
+ * 0.  Several uses of ONE weight in a backward pass (the weight-shared scales of MultiScaleDiscriminator, networks.py:330-365; an
+ * encoder applied twice) may then write their slabs behind each other into one workspace -- partial(d_i, ..., ws + used slabs) --
+ * and ONE mt_conv_bwd_weight_finish(d_any, ws, total slabs, dw, accumulate) sums them: one pass over the gradient instead of one
+ * per use. */
+size_t mt_conv_bwd_weight_slab_bytes(const mt_conv_desc* d);
 
 /* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
 int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,

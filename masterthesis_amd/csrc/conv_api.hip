@@ -771,6 +771,14 @@ extern "C" int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, 
   return mt_launch_unpack((const float*)ws, dw, u, nslabs, slab, accumulate, (hipStream_t)st) ? 2 : 0;
 }
 
+// bytes of ONE slab of mt_conv_bwd_weight_partial when its slabs have the generic [rows][taps][channels] form, which depends on
+// the weight's shape only -- so the slabs of several uses of one weight (different N, H, W) may sit behind each other in one
+// workspace and be summed by ONE mt_conv_bwd_weight_finish; 0 for the layers with their own slab forms (7x7 stem, thin 1x1)
+extern "C" size_t mt_conv_bwd_weight_slab_bytes(const mt_conv_desc* d) {
+  if (check_desc(d) || mt_stem_wgrad_ok(d) || mt_pointwise_small(d)) return 0;
+  return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
+}
+
 extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                   void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
   int nslabs = 0;

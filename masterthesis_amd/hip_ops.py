@@ -613,7 +613,8 @@ class _Conv(torch.autograd.Function):
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
-            if gw is not None and not need_b and _wgrad_group_defer(ctx, desc, x, dy, gw):
+            if gw is not None and not need_b and (_wgrad_group_defer(ctx, desc, x, dy, gw)
+                                                  or _wgrad_share_defer(ctx, desc, x, dy, gw)):
                 return dx, None, db, None          # launched with its group (or at the end of this backward pass)
             if gw is not None and (gbw is not None or not need_b):
                 # accumulate in place; autograd gets None for both
@@ -661,14 +662,8 @@ def _wgrad_group_defer(ctx, desc, x, dy, gw):
         _WGRAD_QUEUE["gmax"][key] = gmax
     if gmax < 2:
         return False
-    task = torch._C._current_graph_task_id()
-    if task < 0:
+    if not _wgrad_arm():
         return False                                 # not inside an engine run (backward called by hand): nothing would flush
-    if _WGRAD_QUEUE["armed"] != task:
-        if _WGRAD_QUEUE["pending"]:                  # left over from a backward pass that died before its callback ran
-            flush_wgrad_groups()
-        _WGRAD_QUEUE["armed"] = task
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_groups)
     q = _WGRAD_QUEUE["pending"].setdefault(key, [])
     q.append((ctx, desc, x, dy, gw))
     if len(q) >= gmax:
@@ -680,6 +675,7 @@ def _wgrad_group_launch(items):
     lib = L.load()
     desc = items[0][1]
     G = len(items)
+
     dev = items[0][2].device
     if G == 1:
         ctx, desc, x, dy, gw = items[0]
@@ -705,12 +701,82 @@ def _wgrad_group_launch(items):
         _grad_use_done(it[0])
 
 
+def _wgrad_arm():
+    """-> False outside an autograd engine run; else makes sure this run's end-of-backward callback will flush the queues"""
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False
+    if _WGRAD_QUEUE["armed"] != task:
+        if _WGRAD_QUEUE["pending"]:                  # left over from a backward pass that died before its callback ran
+            flush_wgrad_groups()
+        _WGRAD_QUEUE["armed"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_groups)
+    return True
+
+
+def _wgrad_share_defer(ctx, desc, x, dy, gw):
+    """Several uses of ONE weight in this backward pass (the three scales of a MultiScaleDiscriminator; an encoder applied twice):
+    every use still runs its own split GEMM, but the slabs go behind each other into one workspace and ONE slab sum adds them
+    into param.grad -- the 1024 -> 2048 layer of the multi-scale discriminators reads and re-writes its 134 MB gradient once
+    instead of three times.  A use waits until the weight's last use of the pass has arrived (ctx.counted bookkeeping)."""
+    if not _WGRAD_GROUP_ON[0] or not ctx.counted:
+        return False
+    owner = ctx.owner
+    key = ("owner", id(owner))
+    parked = _WGRAD_QUEUE["pending"].get(key)
+    if parked is None and getattr(owner, "_mt_pending", 0) <= 1:
+        return False                                 # the only use (left) of this weight
+    skey = _desc_key(desc)
+    sb = _WGRAD_QUEUE["gmax"].get(("slab", skey))
+    if sb is None:
+        sb = int(L.load().mt_conv_bwd_weight_slab_bytes(C.byref(desc)))
+        _WGRAD_QUEUE["gmax"][("slab", skey)] = sb
+    if sb == 0 or not _wgrad_arm():
+        return False
+    if parked is None:
+        parked = _WGRAD_QUEUE["pending"].setdefault(key, [])
+    parked.append((ctx, desc, x, dy, gw))
+    if len(parked) >= getattr(owner, "_mt_pending", 0):
+        _wgrad_shared_launch(_WGRAD_QUEUE["pending"].pop(key))
+    return True
+
+
+def _wgrad_shared_launch(items):
+    """partial GEMMs of every use into one workspace, one slab sum (items: uses of one weight, any geometry)"""
+    if len(items) == 1:
+        return _wgrad_group_launch(items)
+    lib = L.load()
+    dev = items[0][2].device
+    gw = items[0][4]
+    sb = int(lib.mt_conv_bwd_weight_slab_bytes(C.byref(items[0][1])))
+    sizes = [int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(it[1]))) for it in items]
+    total = sum((n + sb - 1) // sb * sb for n in sizes)
+    ws = torch.empty((total,), dtype=torch.uint8, device=dev)
+    used = 0
+    ns = C.c_int(0)
+    for it in items:
+        ctx, desc, x, dy, _ = it
+        off = used * sb
+        with _oplog("wgrad", desc, (0,)):
+            L.check(lib.mt_conv_bwd_weight_partial(C.byref(desc), _ptr(x), _ptr(dy), None, C.c_void_p(ws.data_ptr() + off),
+                                                   total - off, 1, 1, C.byref(ns), _stream()), "mt_conv_bwd_weight_partial")
+        used += ns.value
+    with _oplog("wgrad_sum", items[0][1], (0,)):
+        L.check(lib.mt_conv_bwd_weight_finish(C.byref(items[0][1]), _ptr(ws), used, _ptr(gw), 1, _stream()),
+                "mt_conv_bwd_weight_finish")
+    for it in items:
+        _grad_use_done(it[0])
+
+
 def flush_wgrad_groups():
     """launch every deferred weight gradient (autograd engine callback at the end of a backward pass; also safe to call by hand)"""
     _WGRAD_QUEUE["armed"] = None
     pend, _WGRAD_QUEUE["pending"] = _WGRAD_QUEUE["pending"], {}
-    for items in pend.values():
-        _wgrad_group_launch(items)
+    for key, items in pend.items():
+        if isinstance(key, tuple):                   # ("owner", id): uses of one weight
+            _wgrad_shared_launch(items)
+        else:
+            _wgrad_group_launch(items)
 
 
 def _grad_use_done(ctx):

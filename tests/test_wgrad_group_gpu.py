@@ -113,3 +113,36 @@ def test_deferred_queue_groups_inside_backward(hip_device):
         ops.set_fused_grad_accumulation(fused_before)
         for w in ws:
             ops.set_grad_ready_hook(w, None)
+
+
+def test_uses_of_one_weight_share_one_slab_sum(hip_device):
+    """One weight applied at three scales (the MultiScaleDiscriminator pattern, reference networks.py:330-365): with the queue on,
+    the three weight-gradient GEMMs write their slabs into one workspace and ONE slab sum adds them to param.grad."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(4)
+    w = (torch.randn(128, 64, 4, 4) * 0.05).to(hip_device).requires_grad_()
+    xs = [_rnd(4, 64, s, s, seed=30 + s).to(hip_device) for s in (64, 32, 16)]
+    res = {}
+    fused_before = ops._FUSE_WGRAD_ACC[0]
+    ops.set_fused_grad_accumulation(True)
+    try:
+        for on in (False, True):
+            ops.set_wgrad_group(on)
+            fired = []
+            w.grad = torch.zeros_like(w)
+            ops.set_grad_ready_hook(w, lambda p, fired=fired: fired.append(1))
+            ys = [ops.conv2d(x, w, None, stride=2, pad=1, pad_mode="zero", act="lrelu") for x in xs]
+            loss = sum((y.float() ** 2).mean() for y in ys)
+            ops.oplog_start()
+            loss.backward()
+            ev = ops.oplog_stop()
+            res[on] = (w.grad.clone(), [k for k, d, ms in ev if k.startswith("wgrad")], len(fired))
+        assert res[False][1] == ["wgrad"] * 3 and res[True][1] == ["wgrad"] * 3 + ["wgrad_sum"], (res[False][1], res[True][1])
+        assert res[False][2] == 1 and res[True][2] == 1
+        a, b = res[True][0], res[False][0]
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6
+    finally:
+        ops.set_wgrad_group(True)
+        ops.set_fused_grad_accumulation(fused_before)
+        ops.set_grad_ready_hook(w, None)
