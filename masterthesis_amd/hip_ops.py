@@ -665,20 +665,35 @@ def _wgrad_group_defer(ctx, desc, x, dy, gw):
     if not _wgrad_arm():
         return False                                 # not inside an engine run (backward called by hand): nothing would flush
     q = _WGRAD_QUEUE["pending"].setdefault(key, [])
-    q.append((ctx, desc, x, dy, gw))
+    q.append((ctx, desc, x, dy, gw, _park_event()))
     if len(q) >= gmax:
         _wgrad_group_launch(_WGRAD_QUEUE["pending"].pop(key))
     return True
 
 
+def _park_event():
+    """(stream, event) of the moment a weight-gradient problem was parked: its operands are ready on THAT stream"""
+    st = torch.cuda.current_stream()
+    return (st.cuda_stream, st.record_event())
+
+
+def _wait_parked(items):
+    """the launching stream waits for the operands of problems parked from other streams"""
+    cur = torch.cuda.current_stream()
+    for it in items:
+        if it[5][0] != cur.cuda_stream:
+            cur.wait_event(it[5][1])
+
+
 def _wgrad_group_launch(items):
+    _wait_parked(items)
     lib = L.load()
     desc = items[0][1]
     G = len(items)
 
     dev = items[0][2].device
     if G == 1:
-        ctx, desc, x, dy, gw = items[0]
+        ctx, desc, x, dy, gw = items[0][:5]
         nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
         ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
         with _oplog("wgrad", desc, (0,)):
@@ -735,7 +750,7 @@ def _wgrad_share_defer(ctx, desc, x, dy, gw):
         return False
     if parked is None:
         parked = _WGRAD_QUEUE["pending"].setdefault(key, [])
-    parked.append((ctx, desc, x, dy, gw))
+    parked.append((ctx, desc, x, dy, gw, _park_event()))
     if len(parked) >= getattr(owner, "_mt_pending", 0):
         _wgrad_shared_launch(_WGRAD_QUEUE["pending"].pop(key))
     return True
@@ -745,6 +760,7 @@ def _wgrad_shared_launch(items):
     """partial GEMMs of every use into one workspace, one slab sum (items: uses of one weight, any geometry)"""
     if len(items) == 1:
         return _wgrad_group_launch(items)
+    _wait_parked(items)
     lib = L.load()
     dev = items[0][2].device
     gw = items[0][4]
@@ -755,7 +771,7 @@ def _wgrad_shared_launch(items):
     used = 0
     ns = C.c_int(0)
     for it in items:
-        ctx, desc, x, dy, _ = it
+        ctx, desc, x, dy = it[:4]
         off = used * sb
         with _oplog("wgrad", desc, (0,)):
             L.check(lib.mt_conv_bwd_weight_partial(C.byref(desc), _ptr(x), _ptr(dy), None, C.c_void_p(ws.data_ptr() + off),
