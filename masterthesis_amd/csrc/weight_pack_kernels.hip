@@ -221,33 +221,52 @@ __global__ __launch_bounds__(256) void unpack_wave_kernel(const float* __restric
 __global__ __launch_bounds__(256) void unpack_t_kernel(const float* __restrict__ src, float* __restrict__ dw,
                                                        PackParams p, int nsplit, long slab, int accumulate) {
   __shared__ float tile[64 * MT_MAX_TAPS + 64];
-  const int r = blockIdx.x, c0 = blockIdx.y * 64, nt = p.ntaps;
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, nt = p.ntaps, S = nt | 1;
   const int ncl = min(64, p.Cp - c0);
   const float* base = src + ((long)r * nt) * p.Cp + c0;
-  for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
-    const int t = idx >> 6, cl = idx & 63;
-    float a = 0.f;
+  // round 3: 16-byte accesses on both sides (Cp % 8 == 0, so a 64-column block is whole float4s; the output run of a row is
+  // nt * C contiguous floats and 16-byte aligned when nt * C % 4 == 0): a thread sums one float4 of every slab (eight slabs in
+  // flight) -- for 16 taps that is exactly one item per thread -- and the transposed run leaves as float4 read-modify-writes
+  for (int it = threadIdx.x; it < nt * 16; it += 256) {
+    const int t = it >> 4, c4 = it & 15, cl = c4 * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (cl < ncl) {
-      const float* q = base + (long)t * p.Cp + cl;
+      const f32x4* q = reinterpret_cast<const f32x4*>(base + (long)t * p.Cp + cl);
+      const long sstep = slab >> 2;
       int k = 0;
       for (; k + 8 <= nsplit; k += 8) {          // eight slabs in flight, added in index order
-        float v[8];
+        f32x4 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = q[(long)(k + i) * slab];
+        for (int i = 0; i < 8; i++) v[i] = q[(long)(k + i) * sstep];
 #pragma unroll
         for (int i = 0; i < 8; i++) a += v[i];
       }
-      for (; k < nsplit; k++) a += q[(long)k * slab];
+      for (; k < nsplit; k++) a += q[(long)k * sstep];
     }
-    tile[cl * nt + t + (cl >> 5)] = a;      // +1 float of padding per 32 columns against bank conflicts
+#pragma unroll
+    for (int e = 0; e < 4; e++) tile[(cl + e) * S + t] = a[e];   // odd row stride: the transposing writes spread over the banks
   }
   __syncthreads();
   const int nvalid = min(64, p.C - c0);
   float* out = dw + (long)r * p.sr + (long)c0 * nt;
-  for (int idx = threadIdx.x; idx < nvalid * nt; idx += 256) {
-    const int cl = idx / nt;
-    const float v = tile[idx + (cl >> 5)];
-    out[idx] = accumulate ? out[idx] + v : v;
+  const int total = nvalid * nt;
+  if ((((size_t)out) & 15) == 0 && (total & 3) == 0) {
+    for (int i4 = threadIdx.x; i4 < (total >> 2); i4 += 256) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int idx = i4 * 4 + e, cl = idx / nt;
+        v[e] = tile[cl * S + (idx - cl * nt)];
+      }
+      f32x4* o = reinterpret_cast<f32x4*>(out) + i4;
+      *o = accumulate ? *o + v : v;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+      const int cl = idx / nt;
+      const float v = tile[cl * S + (idx - cl * nt)];
+      out[idx] = accumulate ? out[idx] + v : v;
+    }
   }
 }
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
