@@ -266,6 +266,9 @@ class ContentDiscriminator(nn.Module):
         return ops.global_avg_pool(ops.conv2d(h, head.weight, head.bias))
 
 
+_MSD_LAYER_MAJOR = [__import__("os").environ.get("MT_MSD_LAYER_MAJOR", "1") != "0"]
+
+
 class MultiScaleDiscriminator(nn.Module):
     def __init__(self, input_dim, dim=64, n_layers=6, num_domains=2, norm_layer=None, activation="lrelu",
                  padding_type=None, num_scales=3, sn=False):
@@ -284,13 +287,24 @@ class MultiScaleDiscriminator(nn.Module):
         self.pool = _Marker("adaptive_avgpool")
 
     def forward(self, x):
-        outputs = []
-        for _ in range(self.num_scales):
-            h = x
-            for layer in self.model:
-                h = layer(h)
-            dis = ops.conv2d(h, self.dis.weight, self.dis.bias)
-            c = ops.global_avg_pool(ops.conv2d(h, self.cls.weight, self.cls.bias))
-            outputs.append((dis, c))
-            x = ops.avg_pool3s2(x)
-        return outputs
+        if not _MSD_LAYER_MAJOR[0]:
+            outputs = []
+            for _ in range(self.num_scales):
+                h = x
+                for layer in self.model:
+                    h = layer(h)
+                dis = ops.conv2d(h, self.dis.weight, self.dis.bias)
+                c = ops.global_avg_pool(ops.conv2d(h, self.cls.weight, self.cls.bias))
+                outputs.append((dis, c))
+                x = ops.avg_pool3s2(x)
+            return outputs
+        # layer-major order (same operations, same results): the scales share the weights, and the deep layers are bound by
+        # streaming them (1024 -> 2048: 67 MB of bf16 per launch) -- the three uses of a layer's weights run back to back while
+        # the Infinity Cache still holds them (autograd runs the backward in the mirrored order)
+        hs = [x]
+        for _ in range(self.num_scales - 1):
+            hs.append(ops.avg_pool3s2(hs[-1]))
+        for layer in self.model:
+            hs = [layer(h) for h in hs]
+        return [(ops.conv2d(h, self.dis.weight, self.dis.bias),
+                 ops.global_avg_pool(ops.conv2d(h, self.cls.weight, self.cls.bias))) for h in hs]
