@@ -143,7 +143,7 @@ size_t mt_conv_bwd_weight_ws_bytes(const mt_conv_desc* d);
  * the parameter's .grad and skip a separate accumulation pass). */
 int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw,
                        float* dbias, void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
-/* Grouped weight gradient: G (2..4) convolutions OF THE SAME DESCRIPTOR in one launch (reference: the weight gradients
+/* Grouped weight gradient: G (2..8) convolutions OF THE SAME DESCRIPTOR in one launch (reference: the weight gradients
  * autograd computes one by one for nn.Conv2d, blocks.py:131-132,150-151 -- they are leaves of the backward pass, so their
  * order is free).  The 256x256 weight-gradient kernel splits the pixel reduction to fill the chip and writes one fp32 slab
  * of the whole gradient per split (28 for the dominant layer); G problems share the chip with 28 / G splits each.

@@ -805,17 +805,26 @@ static bool wgrad_group_split(const mt_conv_desc* d, int G, int* nsplit, int* mc
   const int ns = 256 / (tiles * G);
   if (ns < 1 || p.M / ns < 512 || ns * tiles * G < 200) return false;
   const int mc = cdiv(cdiv(p.M, ns), 32) * 32;
-  if (mc > mt_wgrad_pipe_max_chunk_compact()) return false;
+  const int mcmax = mt_wgrad_pipe_compact8_ok(p) ? mt_wgrad_pipe_max_chunk_compact8() : mt_wgrad_pipe_max_chunk_compact();
+  if (mc > mcmax) return false;
   *mchunk = mc;
   *nsplit = cdiv(p.M, mc);
   return true;
 }
 extern "C" int mt_conv_bwd_weight_group_max(const mt_conv_desc* d) {
   if (check_desc(d)) return 1;
-  int ns, mc;
-  for (int G = MT_WGRAD_MAX_GROUP; G >= 2; G--)
-    if (wgrad_group_split(d, G, &ns, &mc)) return G;
-  return 1;
+  // the largest group that still fills the chip (G = 7 of the dominant layer: 63 tiles x 4 splits = 252 blocks; G = 8 would
+  // leave 216), else the largest that fits at all
+  int ns, mc, best = 1;
+  for (int G = MT_WGRAD_MAX_GROUP; G >= 2; G--) {
+    if (!wgrad_group_split(d, G, &ns, &mc)) continue;
+    if (best == 1) best = G;
+    WgradParams p;
+    wgrad_params(d, nullptr, nullptr, &p);
+    const int tiles = (p.CaRows / 256) * (p.nchunks * vec(d->dtype) / 256);
+    if (ns * tiles * G >= 240) return G;
+  }
+  return best;
 }
 extern "C" size_t mt_conv_bwd_weight_group_ws_bytes(const mt_conv_desc* d, int G) {
   int ns, mc;

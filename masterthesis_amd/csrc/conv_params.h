@@ -71,7 +71,7 @@ struct IgemmParams {
   short dw[MT_MAX_TAPS];
 };
 
-#define MT_WGRAD_MAX_GROUP 4
+#define MT_WGRAD_MAX_GROUP 8
 struct WgradParams {
   const char* a;   // pixel-major [M][Cab bytes]: its channels become output rows
   const char* b;   // gathered NHWC [N][Hi][Wi][Cbb bytes]: (tap, channel) become output columns
@@ -121,6 +121,9 @@ int mt_wgrad_pipe_max_chunk();
 // ... with 16-bit pixel deltas in the per-block table (stride-1 problems whose two pixel grids coincide): twice the pixels per split
 bool mt_wgrad_pipe_compact_ok(const WgradParams& p);
 int mt_wgrad_pipe_max_chunk_compact();
+// ... and with 8-bit deltas (additionally: every tap within 126 pixels of its own pixel): four times the pixels per split
+bool mt_wgrad_pipe_compact8_ok(const WgradParams& p);
+int mt_wgrad_pipe_max_chunk_compact8();
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
 // one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch

@@ -34,11 +34,15 @@ __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
   return r;
 }
 
-// COMPACT (grouped launches, where a split is longer than the 32-bit table holds): the table holds 16-bit PIXEL deltas
-// (gathered pixel - own pixel; stride 1 and coinciding pixel grids, so |delta| <= pad * (W + 1)) and the byte offset is formed
-// in the memory phase (one multiply-add and a select per copy).
-template <bool REFLECT, int NS, bool COMPACT>
+// TB = bits of a table entry.  32: byte offsets (one problem per launch).  16 / 8 (grouped launches, whose splits are longer than
+// the 32-bit table holds): signed PIXEL deltas (gathered pixel - own pixel; stride 1 and coinciding pixel grids, so |delta| <=
+// pad * (W + 1): 8 bits serve maps up to 126 pixels wide at pad 1), the byte offset is formed in the memory phase (one
+// multiply-add and a select per copy); the most negative value marks "no pixel".
+template <bool REFLECT, int NS, int TB>
 __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
+  constexpr bool COMPACT = TB != 32;
+  constexpr unsigned NOPIX = TB == 16 ? 0x8000u : 0x80u;           // table code of "no pixel"
+  constexpr unsigned NOPIX_SX = TB == 16 ? 0xffff8000u : 0xffffff80u;   // ... sign-extended
   constexpr int KP = 32;                    // pixels per k-step = K of one v_mfma_f32_16x16x32_bf16
   constexpr int ROWB = 512;                 // LDS row: 256 bf16 of one pixel
   constexpr int TILE = KP * ROWB / 16;      // u32x4 per operand tile (16 KiB)
@@ -97,15 +101,16 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
           ok = ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
         }
         if constexpr (COMPACT) {
-          if (ok) off = (unsigned)(((n * p.Hi + hi) * p.Wi + wi) - m) & 0xffffu;
-          else off = 0x8000u;
+          if (ok) off = (unsigned)(((n * p.Hi + hi) * p.Wi + wi) - m) & (TB == 16 ? 0xffffu : 0xffu);
+          else off = NOPIX;
         } else {
           if (ok) off = (unsigned)((n * p.Hi + hi) * p.Wi + wi) * (unsigned)p.Cbb + bch_bytes;
         }
       } else if constexpr (COMPACT) {
-        off = 0x8000u;
+        off = NOPIX;
       }
-      if constexpr (COMPACT) reinterpret_cast<unsigned short*>(sT)[i] = (unsigned short)off;
+      if constexpr (TB == 16) reinterpret_cast<unsigned short*>(sT)[i] = (unsigned short)off;
+      else if constexpr (TB == 8) reinterpret_cast<unsigned char*>(sT)[i] = (unsigned char)off;
       else sT[i] = off;
     }
   }
@@ -150,13 +155,14 @@ __global__ __launch_bounds__(512) void wgrad_pipe_kernel(const WgradParams p) {
   const short* const sT16 = reinterpret_cast<const short*>(sT);
   const unsigned cbb = (unsigned)p.Cbb;      // (a local: a lambda that touches p by reference sends the whole parameter block to scratch)
   auto lookup = [&](int i) -> unsigned {
-    if constexpr (COMPACT) return (unsigned)(int)sT16[tpos + srow[i]];      // sign-extended pixel delta, 0xffff8000 = no pixel
+    if constexpr (TB == 16) return (unsigned)(int)sT16[tpos + srow[i]];     // sign-extended pixel delta
+    else if constexpr (TB == 8) return (unsigned)(int)reinterpret_cast<const signed char*>(sT)[tpos + srow[i]];
     else return sT[tpos + srow[i]];
   };
   auto offset_of = [&](int i, unsigned t) -> unsigned {
     if constexpr (COMPACT) {
       const unsigned o = (unsigned)(mbeg + tpos + srow[i] + (int)t) * cbb + bch_bytes + cc16[i];
-      return t == 0xffff8000u ? OOB : o;
+      return t == NOPIX_SX ? OOB : o;
     } else {
       return t + cc16[i];
     }
@@ -280,26 +286,39 @@ bool mt_wgrad_pipe_ok(int dtype, int CaRows, int cpc, long a_bytes, long b_bytes
 }
 int mt_wgrad_pipe_max_chunk() { return MT_WGP_MAXM - 6 * 32; }
 int mt_wgrad_pipe_max_chunk_compact() { return 2 * MT_WGP_MAXM - 6 * 32; }
+int mt_wgrad_pipe_max_chunk_compact8() { return 4 * MT_WGP_MAXM - 6 * 32; }
 bool mt_wgrad_pipe_compact_ok(const WgradParams& p) {
   return p.is == 1 && p.Hi == p.Ho && p.Wi == p.Wo && (long)p.Wi * 4 + 4 < 32000;
 }
+// largest |gathered pixel - own pixel| of the problem's taps (zero / reflection padding never reach further)
+static int wgrad_max_delta(const WgradParams& p) {
+  int m = 0;
+  for (int t = 0; t < p.ntaps; t++) {
+    const int d = abs((int)p.dh[t]) * p.Wi + abs((int)p.dw[t]);
+    m = d > m ? d : m;
+  }
+  return m;
+}
+bool mt_wgrad_pipe_compact8_ok(const WgradParams& p) { return mt_wgrad_pipe_compact_ok(p) && wgrad_max_delta(p) <= 126; }
 
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s) {
   const int ngrp = p.ngroup > 1 ? p.ngroup : 1;
   MT_CHECK(ngrp <= MT_WGRAD_MAX_GROUP, "wgrad_pipe: group of %d", ngrp);
-  const bool compact = p.mchunk > mt_wgrad_pipe_max_chunk();
-  if (compact)
-    MT_CHECK(mt_wgrad_pipe_compact_ok(p) && p.mchunk <= mt_wgrad_pipe_max_chunk_compact(),
+  int tb = 32;
+  if (p.mchunk > mt_wgrad_pipe_max_chunk()) tb = 16;
+  if (p.mchunk > mt_wgrad_pipe_max_chunk_compact()) tb = 8;
+  if (tb == 16)
+    MT_CHECK(mt_wgrad_pipe_compact_ok(p), "wgrad_pipe: pixel chunk %d exceeds the offset table", p.mchunk);
+  if (tb == 8)
+    MT_CHECK(mt_wgrad_pipe_compact8_ok(p) && p.mchunk <= mt_wgrad_pipe_max_chunk_compact8(),
              "wgrad_pipe: pixel chunk %d exceeds the offset table", p.mchunk);
   dim3 grid(p.ntiles * nsplit * ngrp);
   const bool refl = p.pad_mode == MT_PAD_REFLECT;
-  if (compact) {
-    if (refl) hipLaunchKernelGGL((wgrad_pipe_kernel<true, 4, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_pipe_kernel<false, 4, true>), grid, dim3(512), 0, s, p);
-  } else {
-    if (refl) hipLaunchKernelGGL((wgrad_pipe_kernel<true, 4, false>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_pipe_kernel<false, 4, false>), grid, dim3(512), 0, s, p);
-  }
+#define MT_WGP(R, B) hipLaunchKernelGGL((wgrad_pipe_kernel<R, 4, B>), grid, dim3(512), 0, s, p)
+  if (tb == 8) { if (refl) MT_WGP(true, 8); else MT_WGP(false, 8); }
+  else if (tb == 16) { if (refl) MT_WGP(true, 16); else MT_WGP(false, 16); }
+  else { if (refl) MT_WGP(true, 32); else MT_WGP(false, 32); }
+#undef MT_WGP
   MT_LAUNCH_CHECK();
   return 0;
 }

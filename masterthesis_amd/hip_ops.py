@@ -640,6 +640,7 @@ class _Conv(torch.autograd.Function):
 # engine callback (queued with the first deferred problem), so param.grad is complete when backward() returns.
 # MT_WGRAD_GROUP=0 / set_wgrad_group(False): every weight gradient is launched where autograd reaches it.
 _WGRAD_GROUP_ON = [os.environ.get("MT_WGRAD_GROUP", "1") != "0"]
+_WGRAD_GROUP_CAP = int(os.environ.get("MT_WGRAD_GROUP_MAX", "8"))       # (A/B runs: cap the group size)
 _WGRAD_QUEUE = {"pending": {}, "armed": None, "gmax": {}}      # armed: id of the autograd graph task whose callback will flush
 
 
@@ -658,7 +659,7 @@ def _wgrad_group_defer(ctx, desc, x, dy, gw):
     key = _desc_key(desc)
     gmax = _WGRAD_QUEUE["gmax"].get(key)
     if gmax is None:
-        gmax = int(L.load().mt_conv_bwd_weight_group_max(C.byref(desc)))
+        gmax = min(int(L.load().mt_conv_bwd_weight_group_max(C.byref(desc))), _WGRAD_GROUP_CAP)
         _WGRAD_QUEUE["gmax"][key] = gmax
     if gmax < 2:
         return False

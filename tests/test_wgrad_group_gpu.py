@@ -16,13 +16,15 @@ def _rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
 
 
-# name, N, C, H, W, pad_mode, G       (the last two run the 16-bit pixel-delta table: splits longer than 6976 pixels)
+# name, N, C, H, W, pad_mode, G       (k1_*: splits longer than 6976 pixels run the 16-bit / 8-bit pixel-delta tables)
 CASES = [
     ("small_reflect_g4", 4, 256, 32, 32, "reflect", 4),
     ("small_zero_g2", 8, 256, 32, 32, "zero", 2),
     ("small_reflect_g3", 8, 256, 32, 32, "reflect", 3),
     ("k1_reflect_g4", 16, 256, 64, 64, "reflect", 4),
     ("k1_zero_g3", 16, 256, 64, 64, "zero", 3),
+    ("k1_reflect_g7", 16, 256, 64, 64, "reflect", 7),       # 4 splits of 16384 pixels: the 8-bit delta table
+    ("k1n32_zero_g4", 32, 256, 64, 64, "zero", 4),          # 7 splits of 18725 pixels: 8-bit deltas, zero padding
 ]
 
 
@@ -64,7 +66,7 @@ def test_group_matches_single_and_reference(case, hip_device):
         err = (got - ref).abs().max().item()
         assert err <= 2e-5 * ref.abs().max().item() + 1e-4, (name, g, err, ref.abs().max().item())
     # fp32 CPU reference of the first and the last problem (the operands are bf16-exact, products are exact in fp32)
-    for g in (0, G - 1):
+    for g in ((0, G - 1) if N <= 16 else (G - 1,)):
         x = ops.to_nchw_f32(xs[g]).cpu()
         dy = ops.to_nchw_f32(dys[g]).cpu()
         xp = F.pad(x, (1, 1, 1, 1), mode="reflect") if pad_mode == "reflect" else x
@@ -103,7 +105,13 @@ def test_deferred_queue_groups_inside_backward(hip_device):
             ev = ops.oplog_stop()
             groups = sorted(d[16] for k, d, ms in ev if k == "wgrad" and len(d) > 16)
             res[on] = ([w.grad.clone() for w in ws], ops.to_nchw_f32(x.grad), groups, sorted(fired))
-        assert res[False][2] == [] and res[True][2] == [2, 4], (res[False][2], res[True][2])
+        # six problems: full groups as they fill up, the rest from the engine callback
+        from masterthesis_amd import _lib as L
+        d = L.ConvDesc(L.MT_BF16, 0, 8, 32, 32, 256, 256, 3, 3, 1, 1, L.PAD_REFLECT, 0, L.ACT_RELU, 0.01)
+        gmax = int(L.load().mt_conv_bwd_weight_group_max(C.byref(d)))
+        assert gmax >= 4
+        assert res[False][2] == [] and sum(res[True][2]) == 6 and max(res[True][2]) <= gmax and len(res[True][2]) <= 2, \
+            (res[False][2], res[True][2], gmax)
         assert res[True][3] == sorted(id(w) for w in ws) == res[False][3]
         assert torch.equal(res[True][1], res[False][1])
         for a, b in zip(res[True][0], res[False][0]):
