@@ -301,6 +301,13 @@ int mt_sn_scale_bwd(const float* G, const float* Weff, const float* u, const flo
 /* AvgPool2d(3, stride 2, pad 1, count_include_pad=False) (networks.py:447) */
 int mt_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
+/* Patches of a 4x4 / stride 2 / zero-padding 1 convolution (nn.Conv2d(.., 4, 2, 1), the layers of MultiScaleDiscriminator,
+ * networks.py:330-365) as a batch of 4x4 mini-images: col [N*(H/2)*(W/2)][4][4][Cp] with col[(n,ho,wo)][a][b] = x[n][2ho-1+a]
+ * [2wo-1+b] (zeros outside).  The same weights applied as a 4x4 / stride 4 / padding 0 convolution to the mini-images give the
+ * original outputs, so inputs of DIFFERENT sizes that share a weight can run as one batch.  bwd: dx = the adjoint (each input
+ * pixel sums the at most four patch cells that copied it).  H, W even. */
+int mt_patch4s2_fwd(int dtype, const void* x, void* col, int N, int H, int W, int Cp, mt_stream_t s);
+int mt_patch4s2_bwd(int dtype, const void* dcol, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
 /* AdaptiveAvgPool2d(1): y fp32 [N][C] (logical channels). */
 int mt_gap_fwd(int dtype, const void* x, float* y, int N, int HW, int C, int Cp, mt_stream_t s);
 int mt_gap_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, int Cp, mt_stream_t s);

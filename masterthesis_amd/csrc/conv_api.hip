@@ -629,7 +629,8 @@ static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, 
       const int tiles = (rows / 256) * (cols / 256);
       // one round of 256 blocks; two or four rounds when a split would not fit the per-block pixel-offset table
       for (int rounds = 1; rounds <= 4; rounds *= 2) {
-        const int ns = rounds * 256 / tiles;
+        int ns = rounds * 256 / tiles;
+        if (ns < 1 && tiles <= 1024 && M <= mt_wgrad_pipe_max_chunk()) ns = 1;     // few pixels, many tiles: whole rounds of tiles
         if (ns < 1 || M / ns < 512) break;
         const int mc = cdiv(cdiv(M, ns), 32) * 32;
         if (mc <= mt_wgrad_pipe_max_chunk()) {

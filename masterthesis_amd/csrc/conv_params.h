@@ -137,7 +137,7 @@ struct PackEntry {
 int mt_launch_pack_multi(const PackEntry* dev_table, int n, int total_blocks, hipStream_t s);
 // grouped variant (weight_pack_kernels.hip): ONE coalesced read of a weight tensor [D0][D1][kh][kw] per 32 x 32 tile of
 // (d0, d1), all of the tensor's pack images written from the LDS copy in 64-byte runs
-#define MT_PACK_GROUP_OUTS 6
+#define MT_PACK_GROUP_OUTS 20      // (a 4x4 / stride 4 data gradient has 16 one-tap phase images)
 struct PackOut {
   void* out;
   int rows_d0;      // image rows are d0 (else d1)

@@ -393,6 +393,81 @@ extern "C" int mt_avgpool3s2_bwd(int dtype, const void* src, void* dst, int N, i
   POOL_LAUNCH(avgpool3s2_kernel, true, (long)N * H * W);
 }
 
+// ---- patches of a 4x4 / stride 2 / zero-padding 1 convolution as 4x4 mini-images (round 3) --------------------------------------
+// col[(n, ho, wo)][a][b][c] = x[n][2 ho - 1 + a][2 wo - 1 + b][c] (0 outside): the [N Ho Wo][4][4][Cp] result is a batch of
+// 4x4 images, on which the SAME weights applied as a 4x4 / stride 4 / no padding convolution give the original outputs.  The
+// weight-shared scales of a multi-scale discriminator (networks.py:330-365) become ONE batch of mini-images for their deep,
+// weight-streaming-bound layers: one pass over 67 MB of weights instead of three, one weight-gradient slab instead of three.
+// BWD: dx[n][h][w] = sum of the (at most four) patch cells that copied it.
+template <bool BF16, bool BWD>
+__global__ void patch4s2_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int N, int H, int W, int cchunks) {
+  constexpr int V = Elem<BF16>::V;
+  const int Ho = H >> 1, Wo = W >> 1;
+  if constexpr (!BWD) {
+    const long total = (long)N * Ho * Wo * 16 * cchunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int cq = (int)(i % cchunks);
+      long t = i / cchunks;
+      const int b = (int)(t & 3), a = (int)((t >> 2) & 3);
+      t >>= 4;
+      const int wo = (int)(t % Wo); t /= Wo;
+      const int ho = (int)(t % Ho);
+      const int n = (int)(t / Ho);
+      const int h = 2 * ho - 1 + a, w = 2 * wo - 1 + b;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = src[(((long)n * H + h) * W + w) * cchunks + cq];
+      dst[i] = v;
+    }
+  } else {
+    const long total = (long)N * H * W * cchunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int cq = (int)(i % cchunks);
+      long t = i / cchunks;
+      const int w = (int)(t % W); t /= W;
+      const int h = (int)(t % H);
+      const int n = (int)(t / H);
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; e++) acc[e] = 0.f;
+      // h = 2 ho - 1 + a: a has the parity of h + 1
+#pragma unroll
+      for (int ia = 0; ia < 2; ia++) {
+        const int a = ((h + 1) & 1) + 2 * ia, ho = (h + 1 - a) >> 1;
+        if ((unsigned)ho >= (unsigned)Ho) continue;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+          const int b = ((w + 1) & 1) + 2 * ib, wo = (w + 1 - b) >> 1;
+          if ((unsigned)wo >= (unsigned)Wo) continue;
+          float f[V];
+          Elem<BF16>::unpack(src[((((long)n * Ho + ho) * Wo + wo) * 16 + a * 4 + b) * cchunks + cq], f);
+#pragma unroll
+          for (int e = 0; e < V; e++) acc[e] += f[e];
+        }
+      }
+      dst[i] = Elem<BF16>::pack(acc);
+    }
+  }
+}
+template <bool BWD>
+static int launch_patch4s2(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, hipStream_t s) {
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  MT_CHECK(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && Cp % 8 == 0, "patch4s2: %d x %d x %d x %d", N, H, W, Cp);
+  const long total = BWD ? (long)N * H * W * (Cp / V) : (long)N * (H / 2) * (W / 2) * 16 * (Cp / V);
+  const int blocks = (int)min((long)8192, (total + 255) / 256);
+  if (dtype == MT_BF16)
+    hipLaunchKernelGGL((patch4s2_kernel<true, BWD>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, Cp / V);
+  else
+    hipLaunchKernelGGL((patch4s2_kernel<false, BWD>), dim3(blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, N, H, W, Cp / V);
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mt_patch4s2_fwd(int dtype, const void* x, void* col, int N, int H, int W, int Cp, mt_stream_t s) {
+  return launch_patch4s2<false>(dtype, x, col, N, H, W, Cp, (hipStream_t)s);
+}
+extern "C" int mt_patch4s2_bwd(int dtype, const void* dcol, void* dx, int N, int H, int W, int Cp, mt_stream_t s) {
+  return launch_patch4s2<true>(dtype, dcol, dx, N, H, W, Cp, (hipStream_t)s);
+}
+
 // AdaptiveAvgPool2d(1): one block per (n, channel slab); fp32 output [N][C]
 template <bool BF16>
 __global__ void gap_fwd_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int HW, int cchunks, int C) {

@@ -1359,6 +1359,63 @@ class _Pool(torch.autograd.Function):
         return dx, None
 
 
+class _Patch4s2Multi(torch.autograd.Function):
+    """Patches of a 4x4 / stride 2 / zero-padding 1 convolution of several inputs (same channels, any even sizes) as ONE batch
+    of 4x4 mini-images [sum N_i Ho_i Wo_i, C, 4, 4] (mt_patch4s2_fwd); backward = the adjoint per input."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        lib = L.load()
+        xs = [canon(x) for x in xs]
+        Cc, dt, dev = xs[0].shape[1], xs[0].dtype, xs[0].device
+        for x in xs:
+            if x.shape[1] != Cc or x.dtype != dt or x.shape[2] % 2 or x.shape[3] % 2:
+                raise RuntimeError(f"patch4s2: inputs must share channels / type and have even sizes, got {tuple(x.shape)}")
+        counts = [x.shape[0] * (x.shape[2] // 2) * (x.shape[3] // 2) for x in xs]
+        col = new_act(sum(counts), Cc, 4, 4, dt, dev)
+        row = 16 * padc(Cc) * col.element_size()
+        off = 0
+        for x, n in zip(xs, counts):
+            L.check(lib.mt_patch4s2_fwd(_mt(dt), _ptr(x), C.c_void_p(col.data_ptr() + off * row), x.shape[0], x.shape[2],
+                                        x.shape[3], padc(Cc), _stream()), "mt_patch4s2_fwd")
+            off += n
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.counts = counts
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        lib = L.load()
+        dcol = canon(dcol)
+        Cc = dcol.shape[1]
+        row = 16 * padc(Cc) * dcol.element_size()
+        outs, off = [], 0
+        for (N, _, H, W), n, need in zip(ctx.shapes, ctx.counts, ctx.needs_input_grad):
+            dx = None
+            if need:
+                dx = new_act(N, Cc, H, W, dcol.dtype, dcol.device)
+                L.check(lib.mt_patch4s2_bwd(_mt(dcol.dtype), C.c_void_p(dcol.data_ptr() + off * row), _ptr(dx), N, H, W,
+                                            padc(Cc), _stream()), "mt_patch4s2_bwd")
+            outs.append(dx)
+            off += n
+        return tuple(outs)
+
+
+def patch4s2_multi(xs):
+    """[x_0, x_1, ...] (NCHW, same C, even H / W) -> the 4x4 mini-image batch of their 4x4 / stride 2 / pad 1 patches"""
+    return _Patch4s2Multi.apply(*xs)
+
+
+def split_pixels(y, shapes):
+    """y [sum N_i H_i W_i, C, 1, 1] (one output pixel per mini-image) -> views [N_i, C, H_i, W_i] of the same memory"""
+    outs = []
+    parts = torch.split(y, [n * h * w for n, h, w in shapes], dim=0)
+    for part, (n, h, w) in zip(parts, shapes):
+        c = part.shape[1]
+        outs.append(part.permute(0, 2, 3, 1).reshape(n, h, w, c).permute(0, 3, 1, 2))
+    return outs
+
+
 class _Upsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -14,7 +14,7 @@ import torch.nn as nn
 from ... import hip_ops as ops
 from .blocks import (AdaINResnetBlock, ConvBlock, DecResnetBlock, DownResnetBlock, ResnetBlock, UpsampleBlock,
                      _Marker, _expand_planes)
-from .functions import get_activation_layer
+from .functions import conv_weight, get_activation_layer
 from .misc import GaussianNoiseLayer, random_source
 
 
@@ -266,6 +266,8 @@ class ContentDiscriminator(nn.Module):
         return ops.global_avg_pool(ops.conv2d(h, head.weight, head.bias))
 
 
+_MSD_MERGE_FACTOR = float(__import__("os").environ.get("MT_MSD_MERGE_FACTOR", "2"))   # patch elements <= factor x weight elements
+_MSD_MERGE = [__import__("os").environ.get("MT_MSD_MERGE", "1") != "0"]
 _MSD_LAYER_MAJOR = [__import__("os").environ.get("MT_MSD_LAYER_MAJOR", "1") != "0"]
 
 
@@ -286,6 +288,33 @@ class MultiScaleDiscriminator(nn.Module):
         self.cls = nn.Conv2d(dim, num_domains, 1, 1, 0)
         self.pool = _Marker("adaptive_avgpool")
 
+    @staticmethod
+    def _mergeable(layer, hs):
+        """A deep layer whose time is streaming its weights (1024 -> 2048: 67 MB of bf16 per launch, three launches for three
+        scales) and whose patches are small next to them: its scales run as ONE batch of 4x4 mini-images (ops.patch4s2_multi)
+        through the same weights as a 4x4 / stride 4 convolution -- same products, one pass over the weights, one weight
+        gradient.  Not with spectral norm (its power iteration runs once per CALL in the reference) or a norm layer."""
+        if not (_MSD_MERGE[0] and len(hs) > 1 and isinstance(layer, ConvBlock) and hs[0].is_cuda):
+            return False
+        conv = layer.block[layer._ci]
+        if (not isinstance(conv, nn.Conv2d) or getattr(conv, "_mt_sn", None) is not None or layer.norm is not None
+                or layer.pad_mode != "zero"):
+            return False
+        if conv.kernel_size != (4, 4) or layer.stride != 2 or layer.padding != 1:
+            return False
+        if any(h.shape[2] % 2 or h.shape[3] % 2 for h in hs):
+            return False
+        ci, co = conv.in_channels, conv.out_channels
+        patch_elems = sum(h.shape[0] * (h.shape[2] // 2) * (h.shape[3] // 2) for h in hs) * 16 * ci
+        return patch_elems <= _MSD_MERGE_FACTOR * co * ci * 16 and ci % 8 == 0
+
+    @staticmethod
+    def _merged(layer, hs):
+        conv = layer.block[layer._ci]
+        col = ops.patch4s2_multi(hs)
+        y = ops.conv2d(col, conv_weight(conv, layer.training), conv.bias, stride=4, pad=0, pad_mode="zero", act=layer.act)
+        return ops.split_pixels(y, [(h.shape[0], h.shape[2] // 2, h.shape[3] // 2) for h in hs])
+
     def forward(self, x):
         if not _MSD_LAYER_MAJOR[0]:
             outputs = []
@@ -305,6 +334,6 @@ class MultiScaleDiscriminator(nn.Module):
         for _ in range(self.num_scales - 1):
             hs.append(ops.avg_pool3s2(hs[-1]))
         for layer in self.model:
-            hs = [layer(h) for h in hs]
+            hs = self._merged(layer, hs) if self._mergeable(layer, hs) else [layer(h) for h in hs]
         return [(ops.conv2d(h, self.dis.weight, self.dis.bias),
                  ops.global_avg_pool(ops.conv2d(h, self.cls.weight, self.cls.bias))) for h in hs]

@@ -257,3 +257,81 @@ def test_batched_weight_pack_equals_single_pack(case, dtype, hip_device):
     torch.cuda.synchronize()
     for which, a, b in zip(("fwd", "bwd_data"), singles, packs):
         assert torch.equal(a, b), f"{which}: batched pack differs in {(a != b).sum().item()} of {a.numel()} bytes"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch4s2_multi_is_the_unfold_of_a_4x4_stride2_conv(dtype, hip_device):
+    """ops.patch4s2_multi: patches of nn.Conv2d(.., 4, 2, 1) of several inputs as one batch of 4x4 mini-images, so that the
+    SAME weights as a 4x4 / stride 4 convolution reproduce the original outputs (the weight-shared scales of the reference's
+    MultiScaleDiscriminator, networks.py:330-365); backward = the adjoint."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(11)
+        xs = [torch.randn(3, 16, s, t, generator=g).bfloat16().float() for s, t in ((8, 8), (4, 6), (2, 2))]
+        w = (torch.randn(24, 16, 4, 4, generator=g) * 0.1).bfloat16().float()
+        xd = [x.to(hip_device).requires_grad_() for x in xs]
+        wd = w.to(hip_device).requires_grad_()
+        col = ops.patch4s2_multi(xd)
+        counts = [3 * (x.shape[2] // 2) * (x.shape[3] // 2) for x in xs]
+        assert tuple(col.shape) == (sum(counts), 16, 4, 4) and ops.is_canonical(col)
+        # the patches themselves: torch unfold of the zero-padded input
+        ref_cols = []
+        for x in xs:
+            u = torch.nn.functional.unfold(x, 4, padding=1, stride=2)            # [N, C*16, L]
+            ref_cols.append(u.transpose(1, 2).reshape(-1, 16, 4, 4))
+        assert torch.equal(ops.to_nchw_f32(col).cpu(), torch.cat(ref_cols).to(torch.float32))
+        y = ops.conv2d(col, wd, None, stride=4, pad=0, pad_mode="zero", act="lrelu")
+        ys = ops.split_pixels(y, [(3, x.shape[2] // 2, x.shape[3] // 2) for x in xs])
+        xr = [x.clone().requires_grad_() for x in xs]
+        wr = w.clone().requires_grad_()
+        yr = [torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, wr, None, 2, 1), 0.01) for x in xr]
+        gys = [torch.randn(*t.shape, generator=g).bfloat16().float() for t in yr]
+        sum((a * b).sum() for a, b in zip(yr, gys)).backward()
+        sum((a.float() * b.to(hip_device)).sum() for a, b in zip(ys, gys)).backward()
+        tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+        for a, b in zip(ys, yr):
+            assert a.shape == b.shape and ops.is_canonical(a)
+            assert (a.float().cpu() - b).norm() <= tol * b.norm() + 1e-5
+        for a, b in zip(xd, xr):
+            assert (a.grad.float().cpu() - b.grad).norm() <= tol * b.grad.norm() + 1e-5
+        assert (wd.grad.cpu() - wr.grad).norm() <= tol * wr.grad.norm() + 1e-5
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_multi_scale_discriminator_merged_layers_match_per_scale_layers(hip_device):
+    """MultiScaleDiscriminator with its deep layers run on merged mini-image batches (the default) against the per-scale form:
+    outputs and every parameter / input gradient agree (same products, sums in another order; bf16)."""
+    from masterthesis_amd import hip_ops as ops
+    from masterthesis_amd.models.core import networks as nets
+    from masterthesis_amd.models.core.functions import init_weights
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(5)
+    D = nets.MultiScaleDiscriminator(3, dim=16, n_layers=6, num_domains=2)
+    init_weights(D, "normal", 0.05)
+    D = D.to(hip_device)
+    x0 = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(6)).to(hip_device)
+    res = {}
+    try:
+        for on in (False, True):
+            nets._MSD_MERGE[0] = on
+            for p in D.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            outs = D(x)
+            merged = [nets.MultiScaleDiscriminator._mergeable(l, [torch.empty(4, l.block[l._ci].in_channels, 2 * s, 2 * s,
+                                                                              device=hip_device) for s in (4, 2, 1)])
+                      for l in D.model]
+            loss = sum((d.float() ** 2).mean() + (c.float() ** 2).mean() for d, c in outs)
+            loss.backward()
+            res[on] = ([t.float().detach().clone() for o in outs for t in o], [p.grad.clone() for p in D.parameters()],
+                       ops.to_nchw_f32(x.grad), merged)
+        assert any(res[True][3]) and not any(res[False][3])
+        for a, b in zip(res[True][0], res[False][0]):
+            assert (a - b).norm() <= 3e-2 * b.norm() + 1e-4
+        for a, b in zip(res[True][1], res[False][1]):
+            assert (a - b).norm() <= 6e-2 * b.norm() + 1e-6
+        assert (res[True][2] - res[False][2]).norm() <= 6e-2 * res[False][2].norm() + 1e-6
+    finally:
+        nets._MSD_MERGE[0] = True
