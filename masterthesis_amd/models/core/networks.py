@@ -266,7 +266,7 @@ class ContentDiscriminator(nn.Module):
         return ops.global_avg_pool(ops.conv2d(h, head.weight, head.bias))
 
 
-_MSD_MERGE_FACTOR = float(__import__("os").environ.get("MT_MSD_MERGE_FACTOR", "5"))   # patch elements <= factor x weight elements
+_MSD_MERGE_FACTOR = float(__import__("os").environ.get("MT_MSD_MERGE_FACTOR", "25"))   # patch elements <= factor x weight elements
 _MSD_MERGE = [__import__("os").environ.get("MT_MSD_MERGE", "1") != "0"]
 _MSD_LAYER_MAJOR = [__import__("os").environ.get("MT_MSD_LAYER_MAJOR", "1") != "0"]
 
