@@ -233,7 +233,8 @@ int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* sca
  * for ADAIN) and writes dx.  scale / shift / mean / rstd: the coef rows of mt_norm_apply_fused / mt_norm_finalize.
  * mt_norm_bwd_onepass_ok says whether a problem qualifies (power-of-two channel chunks, planes that are whole slices, act none /
  * relu / lrelu, at least 128 workgroups) and returns the slice count; otherwise use the three calls.  Launches that share a
- * `sync` buffer must be ordered (one stream). */
+ * `sync` buffer must be ordered (one stream), and no other kernel that waits for sibling workgroups may run on the device at the
+ * same time (one process per GPU): the wait is bounded and a give-up poisons dx with NaN instead of hanging. */
 int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int* slices);
 int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
                         const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,

@@ -682,7 +682,12 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
 #endif
 constexpr int MT_OP_NT = MT_OP_THREADS;
 constexpr int MT_OP_SLICE = MT_OP_THREADS * MT_OP_PAIRS;   // 16-byte chunks of x (and of dy) per workgroup
-constexpr int MT_OP_SPIN = 1 << 22;          // polls before a waiting workgroup gives up and poisons its output (never a hang)
+// Polls (~1 us each) before a waiting workgroup gives up and poisons its output with NaN (never a hang).  A normal wait is the
+// skew between the slices of an image, < 50 us.  ASSUMPTION of the wait: no OTHER kernel that waits for sibling workgroups runs on
+// the device at the same time (one process per GPU, launches of this kernel ordered on one stream) -- two such kernels can hold
+// each other's compute units with partial sets of slices (seen with two processes sharing one GPU: every launch ran into this
+// limit); masterthesis_amd/distributed.py switches the kernel off when ranks share a device.
+constexpr int MT_OP_SPIN = 1 << 19;
 template <int CCH, int NT, int P>
 __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,

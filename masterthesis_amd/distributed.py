@@ -26,6 +26,18 @@ def init_from_env(backend=None):
             backend = os.environ.get("MT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
+            nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if nlocal > torch.cuda.device_count():
+                # several ranks on ONE GPU (rehearsals only): kernels that wait for sibling workgroups (the one-pass norm
+                # backward) assume that no OTHER such kernel runs on the device at the same time -- two processes' partial
+                # sets can hold each other's compute units until the bounded wait gives up and poisons the output.  One
+                # process per GPU (the deployment, and what RCCL requires) never gets there.
+                from . import hip_ops
+                hip_ops.set_norm_onepass(False)
+                if rank == 0:
+                    import sys
+                    print(f"masterthesis_amd: {nlocal} ranks share {torch.cuda.device_count()} GPU(s): one-pass norm backward off",
+                          file=sys.stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
