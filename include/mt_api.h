@@ -76,6 +76,9 @@ long mt_kernel_variant_launches(int which);
  * variant 0 from the start, MT_IGEMM_PATCH=0 variant 2.  Variant 2 has three settings: 0 off, 1 the shapes where it
  * measured faster inside the training step (default), 2 every shape it can run.  MT_IGEMM_PIPE_PATCH=0 disables variant 3. */
 int mt_kernel_variant_enable(int which, int enable);
+/* changes whenever mt_kernel_variant_enable was called: workspace sizes and kernel choices of a descriptor may be cached by a
+ * caller as long as this value stands */
+long mt_kernel_variant_epoch(void);
 static inline int mt_padc(int c) { return (c + 7) & ~7; }
 
 /* ---- convolution family (K1-K8, K12, K17): blocks.py:10-91, networks.py ------------- */

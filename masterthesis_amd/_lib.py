@@ -48,6 +48,7 @@ SIGNATURES = {
     "mt_version": (_i, []),
     "mt_kernel_variant_launches": (C.c_long, [_i]),
     "mt_kernel_variant_enable": (_i, [_i, _i]),
+    "mt_kernel_variant_epoch": (C.c_long, []),
     "mt_conv_out_hw": (_i, [_dp, C.POINTER(_i), C.POINTER(_i)]),
     "mt_conv_pack_bytes": (_z, [_dp, _i]),
     "mt_conv_pack": (_i, [_dp, _i, _p, _p, _p]),

@@ -442,7 +442,10 @@ int mt_pipe_patch_enable(int on);
 extern "C" long mt_kernel_variant_launches(int which) {
   return which == 0 ? g_persist_launches : (which == 1 ? mt_stem_launches() : (which == 2 ? mt_patch_launches() : (which == 3 ? mt_pipe_patch_launches() : -1)));
 }
+static long g_variant_epoch = 0;
+extern "C" long mt_kernel_variant_epoch(void) { return g_variant_epoch; }
 extern "C" int mt_kernel_variant_enable(int which, int enable) {
+  g_variant_epoch++;
   if (which == 1) return mt_stem_enable(enable != 0);
   if (which == 2) return mt_patch_enable(enable);
   if (which == 3) return mt_pipe_patch_enable(enable != 0);

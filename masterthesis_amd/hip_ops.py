@@ -481,6 +481,27 @@ def stats_link_of(t):
     return None if (_DETERMINISTIC[0] or not _STATS_LINK_ON[0]) else getattr(t, "_mt_stats_link", None)
 
 
+_DESC_INFO = {}
+_DESC_CACHE_ON = os.environ.get("MT_DESC_CACHE", "1") != "0"      # (A/B runs)
+
+
+def _desc_info(lib, desc):
+    """Pure functions of a convolution descriptor (output size, workspace sizes, whether the statistics epilogue applies), asked
+    of the library once per descriptor: five ctypes calls per convolution call otherwise -- the small layers of the
+    discriminators are host-bound in the eager step."""
+    key = (bytes(desc), lib.mt_kernel_variant_epoch())       # (workspace sizes follow the kernel-variant switches)
+    info = _DESC_INFO.get(key) if _DESC_CACHE_ON else None
+    if info is None:
+        ho, wo = C.c_int(), C.c_int()
+        L.check(lib.mt_conv_out_hw(C.byref(desc), C.byref(ho), C.byref(wo)), "mt_conv_out_hw")
+        info = (ho.value, wo.value, bool(lib.mt_conv_fwd_stats_fused(C.byref(desc))), int(lib.mt_conv_fwd_ws_bytes(C.byref(desc))),
+                int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc))), int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc))))
+        if len(_DESC_INFO) > 4096:
+            _DESC_INFO.clear()
+        _DESC_INFO[key] = info
+    return info
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
@@ -499,14 +520,13 @@ class _Conv(torch.autograd.Function):
             raise RuntimeError(f"conv: input has {Ci} channels, weight expects {Ciw}")
         desc = L.ConvDesc(_mt(dt), int(transposed), N, H, W, Ci, Co, weight.shape[2], weight.shape[3],
                           stride, pad, pad_mode, out_pad, act, slope)
-        ho, wo = C.c_int(), C.c_int()
-        L.check(lib.mt_conv_out_hw(C.byref(desc), C.byref(ho), C.byref(wo)), "mt_conv_out_hw")
-        y = new_act(N, Co, ho.value, wo.value, dt, x.device)
+        ho, wo, stats_ok, nws_fwd, _, _ = _desc_info(lib, desc)
+        y = new_act(N, Co, ho, wo, dt, x.device)
         pack = _get_pack(owner, weight, desc, L.PACK_FWD)
         b = None if bias is None else _f32c(bias.detach())
         # normalisation statistics of the output are accumulated (atomics) in the GEMM epilogue where the shape allows
         # it; otherwise (and in deterministic mode) the norm layer runs its own reproducible statistics pass
-        want_stats = bool(want_stats and not _DETERMINISTIC[0] and lib.mt_conv_fwd_stats_fused(C.byref(desc)))
+        want_stats = bool(want_stats and not _DETERMINISTIC[0] and stats_ok)
         sums = _zero_stats((N, padc(Co), 2), x.device) if want_stats else None
         timed = _KTIMER["match"] is not None and _KTIMER["match"](desc)
         if timed:
@@ -517,7 +537,7 @@ class _Conv(torch.autograd.Function):
                 L.check(lib.mt_conv_fwd_stats(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(sums),
                                               _stream()), "mt_conv_fwd_stats")
             else:
-                nws = int(lib.mt_conv_fwd_ws_bytes(C.byref(desc)))      # > 0 only for split-K shapes
+                nws = nws_fwd                                           # > 0 only for split-K shapes
                 ws = torch.empty((nws,), dtype=torch.uint8, device=x.device) if nws else None
                 L.check(lib.mt_conv_fwd_ex(C.byref(desc), _ptr(x), _ptr(pack), _ptr(b), _ptr(y), _ptr(ws), nws,
                                            _stream()), "mt_conv_fwd_ex")
@@ -581,7 +601,7 @@ class _Conv(torch.autograd.Function):
             dy = dz
         if ctx.needs_input_grad[0]:
             pack = _get_pack(ctx.owner, weight, desc, L.PACK_BWD_DATA)
-            nws = int(lib.mt_conv_bwd_data_ws_bytes(C.byref(desc)))
+            nws = _desc_info(lib, desc)[4]
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dy.device)
             dx = new_act(*x.shape, dy.dtype, dy.device)
             skip = None
@@ -608,14 +628,14 @@ class _Conv(torch.autograd.Function):
                             "mt_conv_bwd_data")
         need_b = want_b and not bias_done           # bias gradient still to be taken by the weight-gradient call
         if ctx.needs_input_grad[1] or need_b:
-            nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
-            ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
             if gw is not None and not need_b and (_wgrad_group_defer(ctx, desc, x, dy, gw)
                                                   or _wgrad_share_defer(ctx, desc, x, dy, gw)):
                 return dx, None, db, None          # launched with its group (or at the end of this backward pass)
+            nws = _desc_info(lib, desc)[5]
+            ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
             if gw is not None and (gbw is not None or not need_b):
                 # accumulate in place; autograd gets None for both
                 with _oplog("wgrad", desc, (int(need_b),)):
