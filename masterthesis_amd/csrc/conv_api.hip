@@ -353,7 +353,10 @@ static int gather_splitk(int M, int Cout_p, int Cin_p, int ntaps, int V) {
   const int WT = Cout_p > 64 ? 128 : (Cout_p > 32 ? 64 : (Cout_p > 16 ? 32 : 16));
   const int tiles = cdiv(M, 128) * cdiv(Cout_p, WT);
   const int nk = cdiv((long)ntaps * (Cin_p / V), 8);
-  if (tiles > 128 || nk < 48 || ntaps < 2) return 1;
+#ifndef MT_SPLITK_MAX_TILES
+#define MT_SPLITK_MAX_TILES 256      // (round 3: 128 -> 256, the merged mini-image batches of the discriminators: step -0.13 ms)
+#endif
+  if (tiles > MT_SPLITK_MAX_TILES || nk < 48 || ntaps < 2) return 1;
   int ks = 512 / tiles;
   if (ks > ntaps) ks = ntaps;
   if (ks > MT_MAX_PHASES) ks = MT_MAX_PHASES;
