@@ -583,9 +583,14 @@ __global__ __launch_bounds__(256) void thin_dot_kernel(const IgemmParams p) {
     else *reinterpret_cast<float*>(y) = v;
   }
 }
+// (round 3: 512 -> 128 chunks: the 1x1 heads of the multi-scale discriminators -- 2048 -> 1 / 2 channels on 1..16 pixels per image,
+//  24 launches per step -- were ONE 16-channel tile block walking 32 k-steps, 19-24 us each)
+#ifndef MT_THIN_DOT_MIN_CHUNKS
+#define MT_THIN_DOT_MIN_CHUNKS 128
+#endif
 static bool thin_dot_ok(const IgemmParams& p) {
   return p.nphase == 1 && !p.raw && p.stats == nullptr && p.CoRows <= 8 && p.Co <= 8 && p.ph[0].M <= 1024 &&
-         p.ph[0].ntaps * p.cpc >= 512 && p.os == 1;
+         p.ph[0].ntaps * p.cpc >= MT_THIN_DOT_MIN_CHUNKS && p.os == 1;
 }
 
 template <bool BF16>

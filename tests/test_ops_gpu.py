@@ -73,6 +73,9 @@ CONV_CASES = [
     # the discriminator's class head: few pixels x 2 channels x K = 16 taps x 1024 -> streaming dot-product kernel
     ("k4_valid_cls_wide", 4, 1024, 4, 4, 2, 4, 1, 0, "zero", False, None),
     ("k3_thin_bias_lrelu", 2, 512, 6, 6, 5, 3, 1, 1, "zero", True, "lrelu"),
+    # the 1x1 heads of the multi-scale discriminators (2048 -> 1 / 2 channels on a few pixels): streaming dot products too
+    ("k1_head_2048_cls", 8, 2048, 2, 2, 2, 1, 1, 0, "zero", True, None),
+    ("k1_head_2048_dis", 4, 2048, 4, 4, 1, 1, 1, 0, "zero", True, None),
     # few pixels x long K (the discriminators' deep layers): forward split over the filter taps (split-K)
     ("k3s2_deep_splitk", 4, 512, 8, 8, 256, 3, 2, 1, "reflect", True, "lrelu"),
     ("k4s2_msd_splitk", 2, 256, 8, 8, 128, 4, 2, 1, "zero", False, "lrelu"),
