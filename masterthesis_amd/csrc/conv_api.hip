@@ -778,13 +778,25 @@ extern "C" int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, 
 // bytes of ONE slab of mt_conv_bwd_weight_partial when its slabs have the generic [rows][taps][channels] form, which depends on
 // the weight's shape only -- so the slabs of several uses of one weight (different N, H, W) may sit behind each other in one
 // workspace and be summed by ONE mt_conv_bwd_weight_finish; 0 for the layers with their own slab forms (7x7 stem, thin 1x1)
+bool mt_thin_wgrad_ok(const mt_conv_desc* d);                       // conv_aux_kernels.hip
+int mt_launch_thin_wgrad(const mt_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, hipStream_t s);
 extern "C" size_t mt_conv_bwd_weight_slab_bytes(const mt_conv_desc* d) {
-  if (check_desc(d) || mt_stem_wgrad_ok(d) || mt_pointwise_small(d)) return 0;
+  if (check_desc(d) || mt_stem_wgrad_ok(d) || mt_pointwise_small(d) || mt_thin_wgrad_ok(d)) return 0;
   return (size_t)mt_padc(d->Ci) * mt_padc(d->Co) * d->kh * d->kw * sizeof(float);
 }
 
 extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                   void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
+  if (check_desc(d)) return 1;
+  if (dw != nullptr && mt_thin_wgrad_ok(d) && !mt_pointwise_small(d) && !mt_stem_wgrad_ok(d)) {
+    // thin 1x1 head: streaming kernel straight into dw (the bias gradient, if asked for, keeps its own pass)
+    if (dbias != nullptr) {
+      MT_CHECK(ws != nullptr && ws_bytes >= mt_colsum_ws_bytes(mt_padc(d->Co)), "conv_bwd_weight: workspace too small");
+      if (mt_launch_colsum(d->dtype, dy, dbias, (long)d->N * d->H * d->W, mt_padc(d->Co), d->Co, accumulate, ws, ws_bytes,
+                           (hipStream_t)st)) return 2;
+    }
+    return mt_launch_thin_wgrad(d, x, dy, dw, accumulate, (hipStream_t)st) ? 2 : 0;
+  }
   int nslabs = 0;
   const int rc = mt_conv_bwd_weight_partial(d, x, dy, dbias, ws, ws_bytes, accumulate, dw != nullptr, &nslabs, st);
   if (rc) return rc;
