@@ -739,7 +739,10 @@ def _wgrad_group_launch(items):
 
 def _wgrad_arm():
     """-> False outside an autograd engine run; else makes sure this run's end-of-backward callback will flush the queues"""
-    task = torch._C._current_graph_task_id()
+    get_task = getattr(torch._C, "_current_graph_task_id", None)
+    if get_task is None:                             # (a torch without the hook: never park, launch where autograd reaches it)
+        return False
+    task = get_task()
     if task < 0:
         return False
     if _WGRAD_QUEUE["armed"] != task:
