@@ -235,13 +235,21 @@ int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* sca
  * zero), every slice adds the rows in index order (reproducible), derives c1, c2, c3 as mt_norm_bwd_finalize does (dgb [N][2C]
  * for ADAIN) and writes dx.  scale / shift / mean / rstd: the coef rows of mt_norm_apply_fused / mt_norm_finalize.
  * mt_norm_bwd_onepass_ok says whether a problem qualifies (power-of-two channel chunks, planes that are whole slices, act none /
- * relu / lrelu, at least 128 workgroups) and returns the slice count; otherwise use the three calls.  Launches that share a
- * `sync` buffer must be ordered (one stream), and no other kernel that waits for sibling workgroups may run on the device at the
- * same time (one process per GPU): the wait is bounded and a give-up poisons dx with NaN instead of hanging. */
-int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int* slices);
+ * relu / lrelu, at least 128 workgroups, and no more slices per image than min(max_slices, mt_norm_bwd_onepass_capacity()) --
+ * every slice of an image waits for the others, so all of them must be resident together; max_slices <= 0: the capacity) and
+ * returns the slice count; otherwise use the three calls.  mt_norm_bwd_onepass_capacity = occupancy of the kernel x compute units
+ * of the current device.
+ * Contract of the wait: launches that share a `sync` buffer must be ordered (one stream), and no other kernel that waits for
+ * sibling workgroups may run on the device at the same time (one process per GPU; hip_ops orders launches from different
+ * streams behind each other).  The wait is bounded by `spin_limit` polls of ~1 us (<= 0: 2^19): a workgroup that gives up
+ * poisons dx / dgb with NaN AND sets bit 0 of status[0] (status[1] = 1 + its workgroup index; `status`: two zeroed unsigned
+ * words owned by the caller, who reads them at its next device->host copy and treats a set bit as a failed step). */
+int mt_norm_bwd_onepass_capacity(void);
+int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int max_slices, int* slices);
 int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
                         const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,
-                        unsigned* sync, int N, int HW, int C, int Cp, int act, float slope, mt_stream_t s);
+                        unsigned* sync, unsigned* status, int spin_limit, int N, int HW, int C, int Cp, int act, float slope,
+                        mt_stream_t s);
 /* BatchNorm2d(affine, running statistics; functions.py:14-15) on the shared passes: bn_finalize pools the per-(n, c) sums
  * of mt_nc_stats / mt_conv_fwd_stats over the batch (training: batch statistics + momentum update of the running
  * buffers with the unbiased variance; eval: the running buffers) and fills the [N][Cp] coefficient arrays for

@@ -280,7 +280,7 @@ static int launch_colsum(int dtype, const void* dy, float* db, long npix, int Cp
 // partials through LDS) and writes -- or accumulates into -- the OIHW gradient directly: no workspace, no slab sum.
 template <bool BF16, int CO>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
-                                                         float* __restrict__ dw, int M, int cchunks, int Ci, int accumulate) {
+                                                         float* __restrict__ dw, int M, int cchunks, int Ci, int Co, int accumulate) {
   constexpr int V = Elem<BF16>::V;
   constexpr int DYC = 8 / V;                       // 16-byte chunks of a dy pixel (8 padded output channels)
   __shared__ float red[4][CO * V];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const u32x4* __restrict
   if (t < CO * V) {
     const int c = t / V, e = t - c * V;
     const int ci = q * V + e;
-    if (ci < Ci) {
+    if (ci < Ci && c < Co) {                       // CO is Co rounded up to 1 / 2 / 4 / 8: rows >= Co belong to the next tensor
       const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
       float* o = dw + (long)c * Ci + ci;
       *o = accumulate ? *o + v : v;
@@ -327,7 +327,7 @@ int mt_launch_thin_wgrad(const mt_conv_desc* d, const void* x, const void* dy, f
   const int V = d->dtype == MT_BF16 ? 8 : 4;
   const int cchunks = mt_padc(d->Ci) / V, M = d->N * d->H * d->W;
   const int CO = d->Co <= 1 ? 1 : (d->Co <= 2 ? 2 : (d->Co <= 4 ? 4 : 8));
-#define MT_TW(B, C) hipLaunchKernelGGL((thin_wgrad_kernel<B, C>), dim3(cchunks), dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, dw, M, cchunks, d->Ci, accumulate)
+#define MT_TW(B, C) hipLaunchKernelGGL((thin_wgrad_kernel<B, C>), dim3(cchunks), dim3(256), 0, s, (const u32x4*)x, (const u32x4*)dy, dw, M, cchunks, d->Ci, d->Co, accumulate)
   if (d->dtype == MT_BF16) {
     if (CO == 1) MT_TW(true, 1); else if (CO == 2) MT_TW(true, 2); else if (CO == 4) MT_TW(true, 4); else MT_TW(true, 8);
   } else {

@@ -430,6 +430,7 @@ int launch_igemm_persist(IgemmParams& p, int WT, int total, hipStream_t s, bool 
 int launch_igemm_patch(IgemmParams& p, hipStream_t s, bool dry);                                // conv_patch_kernel.hip
 template <bool BF16>
 int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry);               // conv_pipe_patch_kernel.hip
+int launch_igemm_wsreg(IgemmParams& p, hipStream_t s, bool dry);                                // conv_wsreg_kernel.hip
 
 // dry: launch nothing; return 100 if a kernel that honours IgemmParams::y2 (persistent / patch-resident) would take the problem, 101 otherwise
 template <bool BF16>
@@ -438,6 +439,14 @@ static int launch_igemm_t(IgemmParams& p, hipStream_t s, bool dry = false) {
   // MT_IGEMM_FORCE (diagnostics, tools/layer_table.py): 1 = 2-stage kernel only, 2 = 4-wave ring variant wherever legal,
   // 3 = 128x512 tiles wherever legal, 4 = 256x256 tiles wherever legal, 5 = 64-channel tiles for Cout % 128 == 0
   static const int force = getenv("MT_IGEMM_FORCE") ? atoi(getenv("MT_IGEMM_FORCE")) : 0;
+  // short-K / huge-M layers with 64 or 128 output channels: weights stationary in registers, the tile's input patch in LDS,
+  // one barrier per tile (conv_wsreg_kernel.hip, round 4)
+  if constexpr (BF16) {
+    if (force == 0) {
+      const int r = launch_igemm_wsreg(p, s, dry);
+      if (r >= 0) return r;
+    }
+  }
   int PT = 128, WT = p.CoRows > 64 ? 128 : (p.CoRows > 32 ? 64 : (p.CoRows > 16 ? 32 : 16));
   // (the ping-pong kernel steps whole 4-chunk k-steps inside a tap and marks zero lanes with offsets >= 2 GiB)
   const bool pipe_ok = p.cpc % 4 == 0 && p.ph[0].ntaps <= 25 /* MT_PIPE_MAX_TAPS */ && p.x_bytes < 0x7f000000u &&

@@ -659,8 +659,10 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
 // channels), read as whole contiguous lines -- and keeps it IN REGISTERS (16 chunk pairs of x and dy = 128 VGPRs per thread,
 // 256 KiB per CU, every load in flight at once).  It reduces {sum g, sum g x} of its slice in a fixed order, publishes the partial
 // row, waits for the other slices of ITS IMAGE (arrive counter; the only inter-workgroup dependency, between workgroups with
-// neighbouring indices: workgroups are dispatched in index order, so the ones waited for are resident or next in line; a wait
-// that exceeds MT_OP_SPIN polls poisons the output with NaN instead of hanging), adds the image's rows in index order
+// neighbouring indices: workgroups are dispatched in index order, so the ones waited for are resident or next in line -- and
+// mt_norm_bwd_onepass_ok refuses problems with more slices per image than can be resident; a wait that exceeds `spin_limit`
+// polls poisons the output with NaN instead of hanging AND sets the device status word that the host checks with the step's
+// loss scalars: RuntimeError, never a silent NaN), adds the image's rows in index order
 // (bit-reproducible), derives c1, c2, c3 exactly as norm_bwd_finalize_kernel does (slice 0 also writes the AdaIN parameter
 // gradients) and streams dx out of the registers.
 // Measured (tools/bench_norm.py, K1 [16, 256, 64, 64]): 31 us against 45 us for the three launches; inside the step 39 against
@@ -694,8 +696,9 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gb, float* __restrict__ dgb,
                                                                 u32x4* __restrict__ dx, float* __restrict__ part,
-                                                                unsigned* __restrict__ sync, int N, int HW, int C, int S,
-                                                                int mode, int act, float slope) {
+                                                                unsigned* __restrict__ sync, unsigned* __restrict__ status,
+                                                                int spin_limit, int N, int HW, int C, int S, int mode, int act,
+                                                                float slope) {
   constexpr int V = 8, NW = NT / 64;
   static_assert(NT * P == MT_OP_SLICE && NT % CCH == 0 && P % 4 == 0, "slice geometry");
   constexpr int cchunks = CCH;               // 16-byte channel chunks per pixel (power of two, 8..256)
@@ -794,8 +797,14 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
       while (__hip_atomic_load(&sync[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
 #endif
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > MT_OP_SPIN) { ok = 0; break; }
+        if (++spins > spin_limit) { ok = 0; break; }
       }
+    }
+    if (!ok) {
+      // host-visible give-up (hip_ops.raise_on_device_errors reads the words with the step's loss scalars): bit 0 of word 0,
+      // word 1 = 1 + the first workgroup that gave up (diagnostic text of the RuntimeError)
+      atomicOr(&status[0], 1u);
+      atomicCAS(&status[1], 0u, (unsigned)blockIdx.x + 1u);
     }
     ok_flag = ok;
   }
@@ -879,10 +888,27 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
   }
 }
 // Which problems the one-pass kernel takes: bf16, InstanceNorm / AdaIN, a power-of-two number of 16-byte channel chunks (64..2048
-// channels), image planes that are whole 8192-chunk slices, at least half a round of workgroups.
+// channels), image planes that are whole 8192-chunk slices, at least half a round of workgroups, and AT MOST AS MANY SLICES PER
+// IMAGE AS WORKGROUPS OF THIS KERNEL CAN BE RESIDENT (round 4; was a flat 1024): a slice waits for the other slices of its image,
+// so all of them must fit the device together -- with 512 threads x 256 registers a compute unit holds one workgroup, i.e. 256 per
+// device; slices beyond that could never be dispatched while the first ones wait (a guaranteed give-up per launch).
+// mt_norm_bwd_onepass_capacity: occupancy x compute units of the current device (cached per device).  The caller may pass a smaller
+// `max_slices` (e.g. capacity minus the compute units an overlapping collective holds); <= 0 means the capacity itself.
 // *slices = workgroups per image (the part workspace is [N][slices][Cp][2] floats, sync [2][N] zeroed counters).
-extern "C" int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int* slices) {
-  if (slices) *slices = 0;
+extern "C" int mt_norm_bwd_onepass_capacity(void) {
+  static int cap[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cap[dev] > 0) return cap[dev];
+  int per_cu = 0, cus = 0;
+  // (the instantiations differ in LDS only: take the one with the most)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)norm_bwd_onepass_kernel<256, MT_OP_NT, MT_OP_PAIRS>,
+                                                   MT_OP_NT, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  cap[dev] = per_cu * cus;
+  return cap[dev];
+}
+static int onepass_geometry(int dtype, int mode, int N, int HW, int Cp, int act, long* S_out) {
   if (dtype != MT_BF16 || !(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN) || N <= 0 || HW <= 0 || Cp < 8 || Cp % 8) return 0;
   const int cchunks = Cp / 8;
   if ((cchunks & (cchunks - 1)) != 0 || cchunks < 8 || cchunks > 256) return 0;
@@ -890,25 +916,39 @@ extern "C" int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp
   const long chunks = (long)HW * cchunks;
   if (chunks % MT_OP_SLICE != 0) return 0;
   const long S = chunks / MT_OP_SLICE;
-  if (S > 1024 || (long)N * S < 128 || (long)N * S > 0x7fffffffL) return 0;
+  if ((long)N * S < 128 || (long)N * S > 0x7fffffffL) return 0;
+  *S_out = S;
+  return 1;
+}
+extern "C" int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int max_slices, int* slices) {
+  if (slices) *slices = 0;
+  long S = 0;
+  if (!onepass_geometry(dtype, mode, N, HW, Cp, act, &S)) return 0;
+  const int cap = mt_norm_bwd_onepass_capacity();
+  const long lim = max_slices > 0 ? (max_slices < cap ? max_slices : cap) : cap;
+  if (S > lim) return 0;
   if (slices) *slices = (int)S;
   return 1;
 }
 extern "C" int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
                                    const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,
-                                   unsigned* sync, int N, int HW, int C, int Cp, int act, float slope, mt_stream_t st) {
-  int S = 0;
-  MT_CHECK(mt_norm_bwd_onepass_ok(dtype, mode, N, HW, Cp, act, &S), "norm_bwd_onepass: unsupported problem (dtype %d mode %d HW %d Cp %d act %d)",
+                                   unsigned* sync, unsigned* status, int spin_limit, int N, int HW, int C, int Cp, int act,
+                                   float slope, mt_stream_t st) {
+  long S = 0;
+  MT_CHECK(onepass_geometry(dtype, mode, N, HW, Cp, act, &S), "norm_bwd_onepass: unsupported problem (dtype %d mode %d HW %d Cp %d act %d)",
            dtype, mode, HW, Cp, act);
+  MT_CHECK(S <= mt_norm_bwd_onepass_capacity(), "norm_bwd_onepass: %ld slices per image exceed the %d workgroups that can be resident",
+           S, mt_norm_bwd_onepass_capacity());
   MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_onepass: adain needs gb/dgb");
-  MT_CHECK(part != nullptr && sync != nullptr, "norm_bwd_onepass: needs the part / sync workspaces");
+  MT_CHECK(part != nullptr && sync != nullptr && status != nullptr, "norm_bwd_onepass: needs the part / sync / status workspaces");
   MT_CHECK(C <= Cp && C > Cp - 8, "norm_bwd_onepass: C %d does not pad to Cp %d", C, Cp);
+  if (spin_limit <= 0) spin_limit = MT_OP_SPIN;
   hipStream_t s = (hipStream_t)st;
   const int cchunks = Cp / 8;
 #define MT_ONEPASS(CC)                                                                                                       \
   case CC:                                                                                                                   \
-    hipLaunchKernelGGL((norm_bwd_onepass_kernel<CC, MT_OP_NT, MT_OP_PAIRS>), dim3(N * S), dim3(MT_OP_NT), 0, s, (const u32x4*)dy, (const u32x4*)x, scale, \
-                       shift, mean, rstd, gb, dgb, (u32x4*)dx, part, sync, N, HW, C, S, mode, act, slope);                  \
+    hipLaunchKernelGGL((norm_bwd_onepass_kernel<CC, MT_OP_NT, MT_OP_PAIRS>), dim3(N * (int)S), dim3(MT_OP_NT), 0, s, (const u32x4*)dy, (const u32x4*)x, scale, \
+                       shift, mean, rstd, gb, dgb, (u32x4*)dx, part, sync, status, spin_limit, N, HW, C, (int)S, mode, act, slope); \
     break
   switch (cchunks) {
     MT_ONEPASS(8); MT_ONEPASS(16); MT_ONEPASS(32); MT_ONEPASS(64); MT_ONEPASS(128); MT_ONEPASS(256);

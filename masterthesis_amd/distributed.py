@@ -26,7 +26,9 @@ def init_from_env(backend=None):
             backend = os.environ.get("MT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-            nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            # LOCAL_WORLD_SIZE only when the launcher set it (torchrun does): defaulting to the world size would switch the
+            # kernel off on every multi-node run started without it
+            nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
             if nlocal > torch.cuda.device_count():
                 # several ranks on ONE GPU (rehearsals only): kernels that wait for sibling workgroups (the one-pass norm
                 # backward) assume that no OTHER such kernel runs on the device at the same time -- two processes' partial
@@ -133,6 +135,11 @@ class GradReducer:
         self.log = None                 # tests: list that receives ("reduce" | "wait", ...) records
         if self.enabled and torch.cuda.is_available() and os.environ.get("MT_COMM", "torch") == "native":
             self.native = NativeComm(group)
+        if self.enabled and torch.cuda.is_available():
+            # the collectives' kernels are resident while the backward pass runs: kernels that need all slices of an image
+            # resident together (one-pass norm backward) size themselves for the compute units that are left
+            from . import hip_ops
+            hip_ops.set_onepass_reserve(int(os.environ.get("MT_OP_RESERVE_CUS", "64")))
 
     def reduce(self, buffers):
         handles = []

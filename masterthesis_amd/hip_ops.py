@@ -463,17 +463,92 @@ def set_norm_onepass(on):
 
 
 _ONEPASS_SYNC = {}
+_ONEPASS_LAST = {}          # device index -> torch.cuda.Stream of the last one-pass launch
+_ONEPASS_RESERVE = [0]      # compute units left to a kernel that overlaps the backward pass (a live gradient exchange)
+_ONEPASS_SPIN = [int(os.environ.get("MT_OP_SPIN", "0"))]     # poll bound of the wait (0: the library's 2^19)
+_ONEPASS_IMAGES = 8192      # images per launch the counters are sized for (a bigger batch takes the three launches)
+_DEV_STATUS = {}
+
+
+def set_onepass_reserve(cus):
+    """Compute units to leave to OTHER kernels that may be resident during a backward pass (the RCCL kernels of a gradient
+    exchange that overlaps it): the one-pass norm backward then only takes problems whose slices per image fit the rest."""
+    _ONEPASS_RESERVE[0] = max(int(cus), 0)
+
+
+def device_status(dev):
+    """int32 [4] status words of ``dev``, zero while all is well; kernels that can fail on the device (the bounded wait of the
+    one-pass norm backward) set a bit instead of failing silently.  ``models.Model.sync_losses`` copies them to the host together
+    with the loss scalars and calls ``raise_on_device_status`` -- no extra synchronisation.  Never allocated during a graph capture
+    (the zero-fill would be a graph node and the words would sit in the graph's private pool)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _DEV_STATUS.get(idx)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = torch.zeros(4, dtype=torch.int32, device=dev)
+        _DEV_STATUS[idx] = st
+    return st
+
+
+def raise_on_device_status(words, dev=None):
+    """``words``: host copy of ``device_status`` (a sequence of ints).  Raises RuntimeError if a kernel reported a failure and
+    clears the device words so that the next step starts clean."""
+    if not words or not int(words[0]):
+        return
+    if dev is not None:
+        st = _DEV_STATUS.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        if st is not None:
+            st.zero_()
+    what = []
+    if int(words[0]) & 1:
+        what.append(f"one-pass norm backward: workgroup {int(words[1]) - 1} gave up waiting for the other slices of its image "
+                    "(another kernel that waits for sibling workgroups shares the device, or the launch did not fit it); "
+                    "the gradients of this step are NaN.  MT_NORM_ONEPASS=0 selects the three-launch backward")
+    raise RuntimeError("masterthesis_amd device status: " + "; ".join(what or [f"status words {list(words)}"]))
+
+
+def check_device_status(dev=None):
+    """Synchronising form (tests, tools): read the status words now and raise if one is set."""
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
+    st = device_status(dev)
+    if st is not None:
+        raise_on_device_status(st.cpu().tolist(), dev)
 
 
 def _onepass_sync(dev, n):
-    """Per-(device, stream) arrive / leave counters of mt_norm_bwd_onepass ([2][N] uint32, zero; the kernel leaves them zero, so
-    the buffer is allocated once -- a captured graph keeps using the same address -- and grown only for a larger batch)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    """Per-(device, stream) arrive / leave counters of mt_norm_bwd_onepass ([2][N] uint32, zero; the kernel leaves them zero), sized
+    once for ``_ONEPASS_IMAGES`` images so that a captured graph keeps using the same address and nothing is ever (re)allocated
+    while a capture is in progress.  None: no buffer can be had right now -> the caller takes the three launches."""
+    if n > _ONEPASS_IMAGES:
+        return None
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
     buf = _ONEPASS_SYNC.get(key)
-    if buf is None or buf.numel() < 2 * n:
-        buf = torch.zeros(2 * max(n, 64), dtype=torch.int32, device=dev)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.zeros(2 * _ONEPASS_IMAGES, dtype=torch.int32, device=dev)
         _ONEPASS_SYNC[key] = buf
+    # single-stream contract of the kernel (include/mt_api.h): two launches must never be resident together.  A launch from
+    # another stream than the previous one is ordered behind everything that stream holds (no per-launch event on the usual
+    # one-stream path; at the start of a capture the device has been synchronised, and a capture cannot wait on the outside)
+    last = _ONEPASS_LAST.get(dev.index)
+    if last is not None and last.cuda_stream != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
+        cur.wait_stream(last)
+    _ONEPASS_LAST[dev.index] = cur
     return buf
+
+
+def _onepass_slices(lib, mt, mode, N, HW, Cp, act):
+    """slices per image if the one-pass backward takes this problem (0: three launches)"""
+    cap = int(lib.mt_norm_bwd_onepass_capacity()) - _ONEPASS_RESERVE[0]
+    if cap < 1:
+        return 0
+    slices = C.c_int(0)
+    if not lib.mt_norm_bwd_onepass_ok(mt, mode, N, HW, Cp, act, cap, C.byref(slices)):
+        return 0
+    return slices.value
 
 
 def stats_link_of(t):
@@ -677,10 +752,11 @@ def _wgrad_group_defer(ctx, desc, x, dy, gw):
     if not _WGRAD_GROUP_ON[0]:
         return False
     key = _desc_key(desc)
-    gmax = _WGRAD_QUEUE["gmax"].get(key)
+    ckey = (key, L.load().mt_kernel_variant_epoch())          # (the answer follows the kernel-variant switches, as _desc_info)
+    gmax = _WGRAD_QUEUE["gmax"].get(ckey)
     if gmax is None:
         gmax = min(int(L.load().mt_conv_bwd_weight_group_max(C.byref(desc))), _WGRAD_GROUP_CAP)
-        _WGRAD_QUEUE["gmax"][key] = gmax
+        _WGRAD_QUEUE["gmax"][ckey] = gmax
     if gmax < 2:
         return False
     if not _wgrad_arm():
@@ -699,11 +775,15 @@ def _park_event():
 
 
 def _wait_parked(items):
-    """the launching stream waits for the operands of problems parked from other streams"""
+    """the launching stream waits for the operands of problems parked from other streams, and the caching allocator learns that
+    they are in use on the launching stream too (it would otherwise hand x / dy out again as soon as the parking stream is
+    done with them, while the grouped launch still reads them: ADVICE r3)"""
     cur = torch.cuda.current_stream()
     for it in items:
         if it[5][0] != cur.cuda_stream:
             cur.wait_event(it[5][1])
+            it[2].record_stream(cur)
+            it[3].record_stream(cur)
 
 
 def _wgrad_group_launch(items):
@@ -747,7 +827,7 @@ def _wgrad_arm():
         return False
     if _WGRAD_QUEUE["armed"] != task:
         if _WGRAD_QUEUE["pending"]:                  # left over from a backward pass that died before its callback ran
-            flush_wgrad_groups()
+            drop_wgrad_groups()
         _WGRAD_QUEUE["armed"] = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_groups)
     return True
@@ -765,11 +845,11 @@ def _wgrad_share_defer(ctx, desc, x, dy, gw):
     parked = _WGRAD_QUEUE["pending"].get(key)
     if parked is None and getattr(owner, "_mt_pending", 0) <= 1:
         return False                                 # the only use (left) of this weight
-    skey = _desc_key(desc)
-    sb = _WGRAD_QUEUE["gmax"].get(("slab", skey))
+    skey = ("slab", _desc_key(desc), L.load().mt_kernel_variant_epoch())
+    sb = _WGRAD_QUEUE["gmax"].get(skey)
     if sb is None:
         sb = int(L.load().mt_conv_bwd_weight_slab_bytes(C.byref(desc)))
-        _WGRAD_QUEUE["gmax"][("slab", skey)] = sb
+        _WGRAD_QUEUE["gmax"][skey] = sb
     if sb == 0 or not _wgrad_arm():
         return False
     if parked is None:
@@ -817,6 +897,22 @@ def flush_wgrad_groups():
             _wgrad_shared_launch(items)
         else:
             _wgrad_group_launch(items)
+
+
+def drop_wgrad_groups():
+    """Forget every parked weight gradient WITHOUT launching it: the backward pass that parked them died before its end-of-pass
+    callback ran, so they belong to a step that failed -- adding them into param.grad during the next pass would mix two steps
+    (ADVICE r3).  The use counters of their weights are released so that the gradient-ready bookkeeping starts clean."""
+    _WGRAD_QUEUE["armed"] = None
+    pend, _WGRAD_QUEUE["pending"] = _WGRAD_QUEUE["pending"], {}
+    for items in pend.values():
+        for it in items:
+            ctx = it[0]
+            if ctx.counted:
+                ctx.owner._mt_pending = max(getattr(ctx.owner, "_mt_pending", 1) - 1, 0)
+            link = getattr(ctx, "link", None)
+            if link is not None:
+                link.g = None                        # a skip gradient parked by the dead pass
 
 
 def _grad_use_done(ctx):
@@ -1108,18 +1204,21 @@ class _Norm(torch.autograd.Function):
         mt = _mt(x.dtype)
         sl = ctx.slink
         linked = sl is not None and sl.sums is not None and tuple(sl.sums.shape) == (N, Cp, 2)
-        slices = C.c_int(0)
-        if (_NORM_ONEPASS_ON[0] and not linked and ctx.needs_input_grad[0]
-                and lib.mt_norm_bwd_onepass_ok(mt, mode, N, HW, Cp, act, C.byref(slices))):
+        nsl = 0
+        if _NORM_ONEPASS_ON[0] and not linked and ctx.needs_input_grad[0]:
+            nsl = _onepass_slices(lib, mt, mode, N, HW, Cp, act)
+        sync = _onepass_sync(dev, N) if nsl else None
+        status = device_status(dev) if sync is not None else None
+        if status is not None:
             if sl is not None:
                 sl.sums = None
             dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
             dx = new_act(N, Cc, H, W, x.dtype, dev)
-            part = torch.empty((N, slices.value, Cp, 2), dtype=torch.float32, device=dev)
+            part = torch.empty((N, nsl, Cp, 2), dtype=torch.float32, device=dev)
             with _hbm("norm_bwd_onepass", N * HW * Cp * x.element_size() * 3):
                 L.check(lib.mt_norm_bwd_onepass(mt, mode, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]),
-                                                _ptr(coef[3]), _ptr(gbc), _ptr(dgb), _ptr(dx), _ptr(part),
-                                                _ptr(_onepass_sync(dev, N)), N, HW, Cc, Cp, act, slope, _stream()),
+                                                _ptr(coef[3]), _ptr(gbc), _ptr(dgb), _ptr(dx), _ptr(part), _ptr(sync),
+                                                _ptr(status), _ONEPASS_SPIN[0], N, HW, Cc, Cp, act, slope, _stream()),
                         "mt_norm_bwd_onepass")
             dres = dy if ctx.needs_input_grad[4] else None
             link = ctx.cfg[5] if len(ctx.cfg) > 5 else None

@@ -143,9 +143,20 @@ class Model(ABC, nn.Module):
     def sync_losses(self):
         if self._loss_t:
             keys = list(self._loss_t)
-            vals = torch.stack([torch.as_tensor(self._loss_t[k], dtype=torch.float32, device=self.device).reshape(())
-                                for k in keys]).cpu().tolist()      # ONE device->host copy
-            for k, v in zip(keys, vals):
+            vals = [torch.as_tensor(self._loss_t[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys]
+            # the device status words (kernels that can fail on the device set a bit instead of failing silently) ride on the
+            # same device->host copy: a failed step raises here, at the first place the host looks at the device's scalars
+            dev = torch.device(self.device)
+            if dev.type == "cuda" and dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            st = ops.device_status(dev) if dev.type == "cuda" else None
+            flat = torch.stack(vals)
+            if st is not None:
+                flat = torch.cat([flat, st[:2].to(torch.float32)])
+            host = flat.cpu().tolist()                              # ONE device->host copy
+            if st is not None:
+                ops.raise_on_device_status([int(v) for v in host[len(keys):]], dev)
+            for k, v in zip(keys, host):
                 self.loss[k] = v
         return self.loss
 

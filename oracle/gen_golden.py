@@ -266,6 +266,48 @@ def nets_case(name="nets_forward", seed=3):
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def sample_case(name="sample_forward", seed=21, H=60, W=108, dim=8, num_domains=4, bs=2):
+    """``forward_random`` / ``forward_reference`` of the imported reference (adain_model.py:96-109) the way sample.py:79-91 calls
+    them: a non-train model (encoders + decoder only), no ``.eval()`` anywhere (sample.py never calls it: the content encoder's
+    GaussianNoiseLayer stays active, Appendix D-12) -- the draws are recorded.  H x W is a scaled-down 540 x 960 (9:16 with ODD
+    maps after the two stride-2 layers: 15 x 27), so reflection padding / transposed convolutions / the style encoder's pools
+    see the odd sizes of the real sampling resolution.  Only ``torch.cuda.memory_reserved`` is patched (it raises without a GPU)."""
+    import models
+    args = ref_args(mode="test", dim=dim, num_domains=num_domains, batch_size=bs, crop_size=H)
+    torch.manual_seed(seed)
+    M = models.AdaINModel(args)
+    M.initialize()
+    out = {}
+    for net in M.model:
+        _flat(f"init/{net}", M.model[net].state_dict(), out)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = torch.rand(bs, 3, H, W, generator=g) * 2 - 1
+    ref = torch.rand(bs, 3, H, W, generator=g) * 2 - 1
+    z_r = torch.randn(bs, args.latent_dim, generator=g)
+    c = torch.zeros(bs, num_domains)
+    c[:, 2] = 1                                        # sample.py:73-77 load_target: the same target for the whole batch
+    out.update({"in/img": img.numpy(), "in/ref": ref.numpy(), "in/z_r": z_r.numpy(), "in/c": c.numpy()})
+    meta = {"name": name, "model": "AdaINModel", "args": {k: v for k, v in vars(args).items()
+                                                          if isinstance(v, (int, float, str, bool, type(None)))}}
+    reserved = torch.cuda.memory_reserved
+    torch.cuda.memory_reserved = lambda *a, **k: 0
+    try:
+        for tag, call in (("random", lambda: M.forward_random(img, z_r, c)), ("reference", lambda: M.forward_reference(img, ref, c))):
+            rng = []
+            with torch.no_grad(), record_rng(rng):
+                y, secs, gib = call()
+            out[f"{tag}/out"] = y.numpy()
+            for i, t in enumerate(rng):
+                out[f"{tag}/rng/{i}"] = t
+            meta[f"{tag}_rng"] = len(rng)
+    finally:
+        torch.cuda.memory_reserved = reserved
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, rng draws {meta['random_rng']} / {meta['reference_rng']}")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present -- nothing to generate")
@@ -279,6 +321,8 @@ def main():
         return not only or name in only
     if want("nets_forward"):
         nets_case()
+    if want("sample_forward"):
+        sample_case()
     if want("adain_step_d2"):
         step_case("adain_step_d2", "AdaINModel", steps=2, seed=0, num_domains=2, batch_size=1)
     # dim 4: channel counts that are not multiples of 8 (exercises the channel padding)
@@ -298,7 +342,7 @@ def main():
         step_case("adain_step_hinge", "AdaINModel", steps=1, seed=5, num_domains=2, batch_size=1, dim=4,
                   gan_mode="hinge")
     if want("adain_step_nearest"):
-        step_case("adain_step_nearest", "AdaINModel", steps=1, seed=7, num_domains=2, batch_size=1, dim=4,
+        step_case("adain_step_nearest", "AdaINModel", steps=1, seed=7, num_domains=2, batch_size=1, dim=8,
                   up_type="nearest")
     if want("adain_step_sn"):
         # --dis_sn: two steps so the power-iteration vectors carried across calls and steps are pinned too
@@ -317,7 +361,7 @@ def main():
     if want("adain_step_norms"):
         # non-default normalisation flags: LayerNorm in the content encoder, InstanceNorm in the decoder's upsampling
         # blocks and in the discriminators
-        step_case("adain_step_norms", "AdaINModel", steps=1, seed=13, num_domains=2, batch_size=1, dim=4,
+        step_case("adain_step_norms", "AdaINModel", steps=1, seed=13, num_domains=2, batch_size=1, dim=8,
                   enc_norm="layer", dec_norm="instance", dis_norm="instance")
     if want("adain_step_bn"):
         # BatchNorm2d everywhere a norm flag reaches (running statistics land in the post-step checksums); two steps
@@ -334,7 +378,7 @@ def main():
                   ms_dis=True, ms_dim=4)
     if want("adain_step_wgangp"):
         # --gan_mode wgangp: GANLoss returns -mean / +mean (loss.py:53-57); the reference has no gradient penalty
-        step_case("adain_step_wgangp", "AdaINModel", steps=1, seed=16, num_domains=2, batch_size=1, dim=4,
+        step_case("adain_step_wgangp", "AdaINModel", steps=1, seed=16, num_domains=2, batch_size=1, dim=8,
                   gan_mode="wgangp")
     return 0
 

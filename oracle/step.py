@@ -299,5 +299,26 @@ class OracleModel:
         self.update_discriminator(rng)
         self.update_generator(rng)
 
+    # ---- inference (sample.py:79-91 -> adain_model.py:96-109) ----
+    # sample.py never calls .eval(): the content encoder's GaussianNoiseLayer stays ACTIVE while sampling (SURVEY Appendix
+    # D-12), so both calls draw one noise tensor (rng=None: the noise-free eval behaviour)
+    @torch.no_grad()
+    def forward_random(self, img, z_r, c_trg, rng=None):     # adain_model.py:96-101
+        z_c = self.Ec(img.to(self.dtype), rng)
+        return self.Dec(z_c, z_r.to(self.dtype), c_trg.to(self.dtype))
+
+    @torch.no_grad()
+    def forward_reference(self, img_src, img_ref, c_trg, rng=None):   # adain_model.py:103-109
+        z_c = self.Ec(img_src.to(self.dtype), rng)
+        c = c_trg.to(self.dtype)
+        z_s, _, _ = self.Es(img_ref.to(self.dtype), c, rng if rng is not None else _ZeroEps())
+        return self.Dec(z_c, z_s, c)
+
     def state(self):
         return {net: {k: v.detach().clone() for k, v in sd.items()} for net, sd in self.P.items()}
+
+
+class _ZeroEps:
+    """eval-mode reparameterisation: z = mu"""
+    def eps(self, shape):
+        return torch.zeros(tuple(shape))

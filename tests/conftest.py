@@ -15,7 +15,7 @@ def pytest_configure(config):
 # Under `pytest -x` one red test hides everything collected after it (round 2: a self-comparison in test_persist_gpu
 # stopped the driver's run before the 62 reference-fixture tests).  Parity against the reference's recorded fixtures
 # runs FIRST, then the kernels against the fp32 reference of each op, then properties and self-comparisons.
-_ORDER = ["test_step_gpu", "test_stem_gpu", "test_ops_gpu", "test_ops_round2_gpu", "test_patch_gpu", "test_pipe_patch_gpu",
+_ORDER = ["test_fullwidth_step_gpu", "test_step_gpu", "test_sample_gpu", "test_stem_gpu", "test_ops_gpu", "test_ops_round2_gpu", "test_patch_gpu", "test_pipe_patch_gpu",
           "test_oracle_golden", "test_host_cpu"]
 
 

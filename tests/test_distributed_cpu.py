@@ -252,3 +252,34 @@ def test_phase_exchange_and_step_order_two_ranks():
             assert buf == pytest.approx([v * (i + 1) * 1.5 for v in range(1, 6)]), (rank, n, buf)     # mean of 1x and 2x
         assert trace[3][2] == pytest.approx([1.5] * 4)
         assert log[:2] == ["phase", "reduce"] and log.count("wait") == 4
+
+
+def _worker_comm_report(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from masterthesis_amd.distributed import init_from_env
+    init_from_env(backend="gloo")
+    import bench
+    q.put((rank, bench.comm_report(world, torch.device("cpu"))))
+    dist.destroy_process_group()
+
+
+def test_bench_comm_report_counts_the_ranks_of_the_communicator():
+    """bench.py's `comm` block: world size and rank count come from the process group itself -- an all-reduce of
+    ones -- not from the launcher's WORLD_SIZE, so a SCALE run can verify that the collective really spanned N ranks."""
+    import bench
+    assert bench.comm_report(1, torch.device("cpu"))["ranks_seen"] == 1          # no process group: single process
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_comm_report, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        c = out[rank]
+        assert c["backend"] == "gloo" and c["world_from_communicator"] == 2 and c["ranks_seen"] == 2
+        assert c["devices_seen"] == 2 and c["exchange"] == "torch.distributed"

@@ -54,7 +54,7 @@ def test_onepass_matches_three_pass_and_reference(case, hip_device):
     from masterthesis_amd import _lib as L
     expect = bool(L.load().mt_norm_bwd_onepass_ok(L.MT_BF16, L.NORM_INSTANCE if mode == "instance" else L.NORM_ADAIN, N, H * W,
                                                   ops.padc(C), {None: L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU}[act],
-                                                  None))
+                                                  0, None))
     assert expect == (name not in ("adain_relu_c248", "in_relu_small"))
     assert ("norm_bwd_onepass" in used1) == expect, used1.keys()
     assert "norm_bwd_onepass" not in used3 and "norm_bwd_apply" in used3
@@ -86,3 +86,96 @@ def test_onepass_matches_three_pass_and_reference(case, hip_device):
     if mode == "adain":
         num = (dgb1.cpu() - gbr.grad).norm().item()
         assert num <= 8e-2 * gbr.grad.norm().item(), (name, num / gbr.grad.norm().item())   # (test_norms: scale 8 for dgb)
+
+
+def test_slices_per_image_are_bounded_by_residency(hip_device):
+    """every slice of an image waits for the others, so an image may have at most as many slices as workgroups
+    of the kernel can be resident (occupancy x compute units) -- minus what the caller reserves for an overlapping collective."""
+    import ctypes as C
+    from masterthesis_amd import hip_ops as ops, _lib as L
+    lib = L.load()
+    cap = int(lib.mt_norm_bwd_onepass_capacity())
+    props = torch.cuda.get_device_properties(hip_device)
+    assert cap >= props.multi_processor_count and cap % props.multi_processor_count == 0, cap
+    sl = C.c_int(0)
+    # 64 channels (8 chunks per pixel): slices per image = HW / 1024
+    ok = lambda hw, lim: bool(lib.mt_norm_bwd_onepass_ok(L.MT_BF16, L.NORM_INSTANCE, 2, hw, 64, L.ACT_RELU, lim, C.byref(sl)))
+    assert ok(cap * 1024, 0) and sl.value == cap                        # S = capacity: taken
+    assert not ok((cap + 1) * 1024, 0) and sl.value == 0                # S = capacity + 1: refused
+    assert not ok(cap * 1024, cap - 1)                                  # the caller's limit counts
+    assert ok((cap - 64) * 1024, cap - 64) and not ok((cap - 63) * 1024, cap - 64)
+    assert not ok(cap * 1024, 10 * cap) or sl.value == cap              # a limit above the capacity does not raise it
+    assert not ok((cap + 1) * 1024, 10 * cap)
+    # the op layer honours the reserve: a 512 x 512 plane of 64 channels (256 slices) falls back to three launches
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        ops.set_onepass_reserve(64)
+        y, dx, _, _, used = _run(ops, "reserve", 1, 64, 512, 512, "instance", "relu", False, hip_device, True)
+        assert "norm_bwd_onepass" not in used and "norm_bwd_apply" in used
+        ops.set_onepass_reserve(0)
+        y2, dx2, _, _, used2 = _run(ops, "reserve", 1, 64, 512, 512, "instance", "relu", False, hip_device, True)
+        assert ("norm_bwd_onepass" in used2) == (cap >= 256)
+        assert (dx.float() - dx2.float()).abs().max().item() <= 2 ** -7 * dx.float().abs().max().item() + 1e-6
+    finally:
+        ops.set_onepass_reserve(0)
+    ops.check_device_status(hip_device)
+
+
+def test_give_up_reaches_the_host(hip_device):
+    """a wait that gives up must not be a silent NaN.  The arrive counter of one image is preset so that it
+    can never reach the slice count (2^32 - S: the last arrival wraps it to 0), the poll bound is a kernel argument (64 here), and
+    the status word the kernel sets surfaces as a RuntimeError -- through check_device_status and through Model.sync_losses'
+    single device->host copy.  The kernel still terminates and leaves the counters clean."""
+    import ctypes as C
+    from masterthesis_amd import hip_ops as ops, _lib as L
+    lib = L.load()
+    N, Cc, H, W = 8, 256, 64, 64
+    S = (H * W * Cc // 8) // 8192
+    P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    x = ops.canon(_rnd(N, Cc, H, W, seed=1).to(hip_device), torch.bfloat16)
+    dy = ops.canon(_rnd(N, Cc, H, W, seed=2).to(hip_device), torch.bfloat16)
+    coef = torch.ones(4, N, Cc, device=hip_device)
+    dx = torch.empty_like(x)
+    part = torch.empty(N, S, Cc, 2, device=hip_device)
+    sync = torch.zeros(2 * N, dtype=torch.int32, device=hip_device)
+    sync[3] = -S                                    # image 3 can never complete
+    status = torch.zeros(4, dtype=torch.int32, device=hip_device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.mt_norm_bwd_onepass(L.MT_BF16, L.NORM_INSTANCE, P(dy), P(x), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), None,
+                                    None, P(dx), P(part), P(sync), P(status), 64, N, H * W, Cc, Cc, L.ACT_RELU, 0.0, st), "onepass")
+    torch.cuda.synchronize()
+    words = status.cpu().tolist()
+    assert words[0] & 1 and 3 * S < words[1] <= 4 * S, words          # a workgroup of image 3 reported
+    assert int((sync != 0).sum()) == 0                                  # self-cleaning also after a give-up
+    nan_img = torch.isnan(dx.float()).flatten(1).any(1).cpu().tolist()
+    assert nan_img[3] and not any(nan_img[:3]) and not any(nan_img[4:]), nan_img
+    with pytest.raises(RuntimeError, match="one-pass norm backward"):
+        ops.raise_on_device_status(words)
+    # through the op layer: the same failure injected into the module's own status words reaches sync_losses
+    dev_words = ops.device_status(hip_device)
+    dev_words[:2] = torch.tensor([1, 7], dtype=torch.int32, device=hip_device)
+    with pytest.raises(RuntimeError, match="workgroup 6 gave up"):
+        ops.check_device_status(hip_device)
+    assert int(dev_words.abs().sum()) == 0                              # cleared for the next step
+    ops.check_device_status(hip_device)
+
+
+def test_launches_from_two_streams_are_ordered(hip_device):
+    """two one-pass launches must never be resident together.  The op layer orders a launch from another
+    stream behind the stream of the previous launch; results on both streams equal the single-stream ones."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    case = ("in_relu_k1", 8, 256, 64, 64, "instance", "relu", False)
+    _, ref, _, _, used = _run(ops, *case, hip_device, True)
+    assert "norm_bwd_onepass" in used
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for st in (s1, s2):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(_run(ops, *case, hip_device, True)[1])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
+    ops.check_device_status(hip_device)

@@ -76,6 +76,10 @@ CONV_CASES = [
     # the 1x1 heads of the multi-scale discriminators (2048 -> 1 / 2 channels on a few pixels): streaming dot products too
     ("k1_head_2048_cls", 8, 2048, 2, 2, 2, 1, 1, 0, "zero", True, None),
     ("k1_head_2048_dis", 4, 2048, 4, 4, 1, 1, 1, 0, "zero", True, None),
+    # --num_domains 3 / 5 / 6 / 7: the streaming weight-gradient kernel is instantiated for 1 / 2 / 4 / 8 rows
+    ("k1_head_co3", 4, 256, 4, 4, 3, 1, 1, 0, "zero", True, None),
+    ("k1_head_co5", 2, 512, 3, 3, 5, 1, 1, 0, "zero", True, None),
+    ("k1_head_co7", 2, 264, 2, 2, 7, 1, 1, 0, "zero", False, None),
     # few pixels x long K (the discriminators' deep layers): forward split over the filter taps (split-K)
     ("k3s2_deep_splitk", 4, 512, 8, 8, 256, 3, 2, 1, "reflect", True, "lrelu"),
     ("k4s2_msd_splitk", 2, 256, 8, 8, 128, 4, 2, 1, "zero", False, "lrelu"),

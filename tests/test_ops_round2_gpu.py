@@ -335,3 +335,38 @@ def test_multi_scale_discriminator_merged_layers_match_per_scale_layers(hip_devi
         assert (res[True][2] - res[False][2]).norm() <= 6e-2 * res[False][2].norm() + 1e-6
     finally:
         nets._MSD_MERGE[0] = True
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Co", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_thin_head_weight_gradient_stays_inside_its_tensor(Co, accumulate, dtype, hip_device):
+    """thin_wgrad_kernel is instantiated for 1 / 2 / 4 / 8 output rows and used to store all of them; with
+    --num_domains 3, 5, 6, 7 (cls heads 2048 -> D, reference networks.py:452) the extra rows landed on the next parameter of
+    the flat gradient buffer.  A canary region behind dw must stay untouched, in both accumulate modes, and the rows that are
+    written must equal the fp32 reference."""
+    import ctypes as C
+    from masterthesis_amd import hip_ops as ops, _lib as L
+    ops.set_compute_dtype(dtype)
+    lib = L.load()
+    N, Ci, H, W = 2, 512, 3, 3
+    g = torch.Generator().manual_seed(100 + Co)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    desc = L.ConvDesc(L.MT_BF16 if dtype == torch.bfloat16 else L.MT_F32, 0, N, H, W, Ci, Co, 1, 1, 1, 0, L.PAD_ZERO, 0,
+                      L.ACT_NONE, 0.0)
+    xd, dyd = ops.canon(x.to(hip_device)), ops.canon(dy.to(hip_device))
+    n = Co * Ci
+    buf = torch.full((n + 8 * Ci,), 7.0, dtype=torch.float32, device=hip_device)      # dw followed by the canary
+    start = torch.full((n,), 0.5, dtype=torch.float32, device=hip_device)
+    buf[:n] = start
+    nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(desc)))
+    ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=hip_device)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.mt_conv_bwd_weight(C.byref(desc), P(xd), P(dyd), P(buf), None, P(ws), nws, accumulate, st), "thin wgrad")
+    torch.cuda.synchronize()
+    assert (buf[n:] == 7.0).all(), f"Co={Co}: {int((buf[n:] != 7.0).sum())} floats written behind dw"
+    ref = torch.einsum("nohw,nihw->oi", dy, x)
+    got = (buf[:n] - (start if accumulate else 0)).view(Co, Ci).cpu()
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-5

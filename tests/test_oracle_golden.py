@@ -131,3 +131,22 @@ def test_torch_rng_reproduces_reference_draws():
     shapes = [tuple(t.shape) for t in rec.log]
     want = [tuple(z[f"rng/0/{i}"].shape) for i in range(meta["rng_counts"][0])]
     assert shapes == want
+
+
+@pytest.mark.parametrize("which", ["random", "reference"])
+def test_sampling_forward_matches_reference(which):
+    """forward_random / forward_reference (reference adain_model.py:96-109 as sample.py:79-91 calls them: no .eval(), so the
+    content noise is live) recorded from the imported reference on a scaled-down 540 x 960 with odd maps everywhere."""
+    z, meta = load("sample_forward")
+    a = meta["args"]
+    args = step.default_args(**{k: a[k] for k in vars(step.default_args()) if k in a})
+    args.model = "AdaINModel"
+    M = step.OracleModel({n: sub(z, f"init/{n}") for n in ("content_encoder", "style_encoder", "decoder")}, args)
+    inp = sub(z, "in")
+    rng = step.ReplayRng([z[f"{which}/rng/{i}"] for i in range(meta[f"{which}_rng"])])
+    if which == "random":
+        y = M.forward_random(inp["img"], inp["z_r"], inp["c"], rng)
+    else:
+        y = M.forward_reference(inp["img"], inp["ref"], inp["c"], rng)
+    assert rng.i == meta[f"{which}_rng"] == (1 if which == "random" else 2)
+    close(y, z[f"{which}/out"], rtol=1e-4, atol=0.0, what=f"forward_{which}")

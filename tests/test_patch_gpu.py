@@ -57,6 +57,7 @@ def test_patch_kernel_matches_reference_and_replaced_kernels(case, hip_device):
     ops.set_compute_dtype(torch.bfloat16)
     lib = L.load()
     prev = lib.mt_kernel_variant_enable(2, 2)       # every shape the kernel can run (the default takes only the measured wins)
+    prev_ws = lib.mt_kernel_variant_enable(4, 0)    # (round 4: the weight-stationary kernel would take the 64-channel shapes first)
     try:
         (x, w, b, gy), (y1, dx1), used = _run(ops, lib, case, hip_device)
         assert used == case[13], f"patch-kernel launches (forward, backward) = {used}, expected {case[13]}"
@@ -65,6 +66,7 @@ def test_patch_kernel_matches_reference_and_replaced_kernels(case, hip_device):
         assert unused == (0, 0)
     finally:
         lib.mt_kernel_variant_enable(2, prev)
+        lib.mt_kernel_variant_enable(4, prev_ws)
     # against the fp32 reference of the op (element-wise through the device's own activation mask)
     check_against_reference(case[:13], x, w, b, gy, y1, dx1)
     # against the kernels it replaces: same bf16 operands, fp32 accumulation in another order, bf16 outputs

@@ -111,6 +111,7 @@ def test_persistent_matches_per_tile_kernel(case, hip_device):
     prev = lib.mt_kernel_variant_enable(0, 1)
     prev_stem = lib.mt_kernel_variant_enable(1, 0)      # (the 7x7 case is about the gather-GEMM pair, not the direct stem kernel)
     prev_patch = lib.mt_kernel_variant_enable(2, 0)     # (... nor the patch-resident kernel, which takes the stride-1 / scatter shapes first)
+    prev_ws = lib.mt_kernel_variant_enable(4, 0)        # (... nor the weight-stationary kernel of round 4)
     try:
         n0 = lib.mt_kernel_variant_launches(0)
         (x, w, b, gy), (y1, dx1) = _run(ops, case, hip_device)
@@ -123,6 +124,7 @@ def test_persistent_matches_per_tile_kernel(case, hip_device):
         lib.mt_kernel_variant_enable(0, prev)
         lib.mt_kernel_variant_enable(1, prev_stem)
         lib.mt_kernel_variant_enable(2, prev_patch)
+        lib.mt_kernel_variant_enable(4, prev_ws)
     assert torch.equal(y1, y0), f"forward differs: max {(y1 - y0).abs().max().item():.3e}"
     assert torch.equal(dx1, dx0), f"data gradient differs: max {(dx1 - dx0).abs().max().item():.3e}"
     # ... and both against the op's fp32 reference

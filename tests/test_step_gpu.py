@@ -224,10 +224,16 @@ def test_training_step_matches_reference_in_deterministic_mode(name, tmp_path, h
 # `nearest` the d l1_recon_z / d img_random field that comes back through the style encoder has cos -0.28 to the fp32
 # one while the forward image agrees to cos 0.9987, and the decoder's gradient is that field's near-cancelling pixel
 # sum), deterministic but not a statement about the code; their logic is pinned by the fp32 run of the same fixture.
-PHASE4_NARROW = {"adain_step_nearest", "adain_step_norms", "adain_step_wgangp"}
+# Round 4: nearest / norms / wgangp were re-recorded at --dim 8 (no fixture is "width-limited" any more) and now
+# take the general bounds -- measured on the re-recorded fixtures: nearest cos 0.71 / 0.96, ratio 0.97 / 0.74; wgangp cos 0.75 /
+# 0.80, ratio 1.06 / 1.04; `norms` (LayerNorm in the content encoder, InstanceNorm in the decoder's up-sampling blocks: every
+# normalisation of phase 4 subtracts a mean over a near-uniform gradient field) cos 0.63 / 0.65, ratio 0.95 / 0.97: its own cosine
+# bound, the norm window is the general one.
+PHASE4_COS = {"adain_step_norms": (0.55, 0.55)}
 PHASE4_FIXTURES = ["adain_step_d2", "adain_step_d4_b2", "base_step_concat_reparam", "adain_step_lsgan", "adain_step_hinge",
                    "adain_step_ragan", "adain_step_sn", "adain_step_dc", "base_step_concat", "adain_step_dropout",
-                   "base_step_concat_dropout", "adain_step_bn", "adain_step_ms"] + sorted(PHASE4_NARROW)
+                   "base_step_concat_dropout", "adain_step_bn", "adain_step_ms", "adain_step_nearest", "adain_step_norms",
+                   "adain_step_wgangp"]
 
 
 def _phase4_gradients(name, tmp_path, precision):
@@ -268,10 +274,7 @@ def test_bf16_phase4_gradient_tracks_fp32_run_in_deterministic_mode(name, tmp_pa
         ratio = (a.norm() / (b.norm() + 1e-300)).item()
         print(f"MT_DIAG phase4 {name} {net}: bf16 vs fp32 cos {cos:+.3f} ratio {ratio:.3f}")
         assert torch.isfinite(a).all() and a.norm().item() > 0
-        if name in PHASE4_NARROW:
-            assert 0.2 <= ratio <= 2.0, f"{name} {net}: phase-4 gradient norm ratio {ratio:.3f} (width-4 fixture: gross bound only)"
-            continue
-        cos_min = 0.6 if net == "content_encoder" else 0.75
+        cos_min = PHASE4_COS.get(name, (0.6, 0.75))[0 if net == "content_encoder" else 1]
         assert cos >= cos_min, f"{name} {net}: bf16 phase-4 gradient cosine {cos:.3f} to the fp32 run < {cos_min}"
         assert 0.7 <= ratio <= 1.3, f"{name} {net}: bf16 phase-4 gradient norm ratio {ratio:.3f} to the fp32 run"
 

@@ -66,13 +66,14 @@ for (N, Cc, H, W, act, res) in [(16, 256, 64, 64, L.ACT_RELU, False), (16, 256, 
                                                 P(cc[2]), P(y), N, HW, Cp, act, 0.01, st()))
     sl = C.c_int(0)
     t_op = float("nan")
-    if lib.mt_norm_bwd_onepass_ok(L.MT_BF16, L.NORM_INSTANCE, N, HW, Cp, act, C.byref(sl)):
+    if lib.mt_norm_bwd_onepass_ok(L.MT_BF16, L.NORM_INSTANCE, N, HW, Cp, act, 0, C.byref(sl)):
         part1 = torch.empty((N, sl.value, Cp, 2), dtype=torch.float32, device=dev)
         sync = torch.zeros(2 * N, dtype=torch.int32, device=dev)
+        status = torch.zeros(4, dtype=torch.int32, device=dev)
         t_op = timeit(lambda: lib.mt_norm_bwd_onepass(L.MT_BF16, L.NORM_INSTANCE, P(dy), P(x), P(coef[0]), P(coef[1]), P(coef[2]),
-                                                      P(coef[3]), None, None, P(y), P(part1), P(sync), N, HW, Cc, Cp, act, 0.01,
+                                                      P(coef[3]), None, None, P(y), P(part1), P(sync), P(status), 0, N, HW, Cc, Cp, act, 0.01,
                                                       st()))
-        assert int(sync.abs().sum().item()) == 0
+        assert int(sync.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
     print(f"   one-pass backward {t_op:.1f}us ({tbs(3 * nbytes, t_op):.2f} TB/s) vs three-pass {t_sb + t_fb + t_ab:.1f}us")
     print(f"[{N},{Cc},{H},{W}] res={int(res)} nparts={nparts}: stats {t_s:.1f}us ({tbs(nbytes, t_s):.2f} TB/s)  "
           f"finalize {t_f:.1f}us  apply {t_a:.1f}us ({tbs(nbytes * (3 if res else 2), t_a):.2f} TB/s) | bwd stats "
