@@ -228,8 +228,9 @@ int mt_norm_bwd_finalize(int mode, const float* sums2, const float* mean, const 
 int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* scale,
                       const float* shift, const float* c1, const float* c2, const float* c3,
                       void* dx, int N, int HW, int Cp, int act, float slope, mt_stream_t s);
-/* The three backward calls above in ONE launch and ONE pass over dy and x (InstanceNorm / AdaIN, bf16; functions.py:17,
- * norm.py:29-33 backward): a workgroup keeps a slice of an image (8192 sixteen-byte chunks of x and of dy) in registers, the
+/* The three backward calls above in ONE launch and ONE pass over dy and x (InstanceNorm / AdaIN / LayerNorm, bf16; functions.py:17,
+ * norm.py:5-33 backward; LAYER (round 4): gamma [C] or null, dgb = the [N][2][C] per-image scratch of mt_norm_bwd_finalize,
+ * dgamma / dbeta [C] or null -- the images' terms are added in index order by a second, tiny launch): a workgroup keeps a slice of an image (8192 sixteen-byte chunks of x and of dy) in registers, the
  * slices of an image exchange their partial {sum g, sum g x} rows through `part` ([N][slices][Cp][2] floats, need not be
  * initialised) and meet at per-image counters in `sync` ([2][N] unsigned, ZERO before the first launch; the kernel leaves them
  * zero), every slice adds the rows in index order (reproducible), derives c1, c2, c3 as mt_norm_bwd_finalize does (dgb [N][2C]
@@ -247,9 +248,9 @@ int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const float* sca
 int mt_norm_bwd_onepass_capacity(void);
 int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp, int act, int max_slices, int* slices);
 int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
-                        const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,
-                        unsigned* sync, unsigned* status, int spin_limit, int N, int HW, int C, int Cp, int act, float slope,
-                        mt_stream_t s);
+                        const float* mean, const float* rstd, const float* gb, float* dgb, const float* gamma, float* dgamma,
+                        float* dbeta, void* dx, float* part, unsigned* sync, unsigned* status, int spin_limit, int N, int HW,
+                        int C, int Cp, int act, float slope, mt_stream_t s);
 /* BatchNorm2d(affine, running statistics; functions.py:14-15) on the shared passes: bn_finalize pools the per-(n, c) sums
  * of mt_nc_stats / mt_conv_fwd_stats over the batch (training: batch statistics + momentum update of the running
  * buffers with the unbiased variance; eval: the running buffers) and fills the [N][Cp] coefficient arrays for

@@ -86,7 +86,7 @@ SIGNATURES = {
     "mt_norm_bwd_apply": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "mt_norm_bwd_onepass_capacity": (_i, []),
     "mt_norm_bwd_onepass_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _p]),
-    "mt_norm_bwd_onepass": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "mt_norm_bwd_onepass": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "mt_act_fwd": (_i, [_i, _p, _p, _z, _i, _f, _p]),
     "mt_act_bwd": (_i, [_i, _p, _p, _p, _z, _i, _f, _p]),
     "mt_add": (_i, [_i, _p, _p, _p, _z, _p]),

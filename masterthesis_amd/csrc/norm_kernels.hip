@@ -695,6 +695,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gb, float* __restrict__ dgb,
+                                                                const float* __restrict__ gamma,
                                                                 u32x4* __restrict__ dx, float* __restrict__ part,
                                                                 unsigned* __restrict__ sync, unsigned* __restrict__ status,
                                                                 int spin_limit, int N, int HW, int C, int S, int mode, int act,
@@ -831,6 +832,26 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
     }
   }
   __syncthreads();
+  // LayerNorm (the reference's per-sample norm over C, H, W with a per-channel affine: norm.py:5-21): the image's two scalars
+  // LA = sum_c gamma_c S1_c, LB = sum_c gamma_c sum(g xh)_c, reduced in a fixed order (lanes by xor shuffles, waves in index order);
+  // slice 0 leaves the per-image terms of dgamma / dbeta in dgb [N][2][C] (ln_param_grad_kernel adds the images)
+  float LA = 0.f, LB = 0.f;
+  if (mode == MT_NORM_LAYER) {
+    float a = 0.f, b = 0.f;
+    for (int c = tid; c < C; c += NT) {
+      const long i = (long)n * Cp + c;
+      const float S1 = tot[2 * c], S2 = tot[2 * c + 1];
+      const float gxh = rstd[i] * (S2 - mean[i] * S1);
+      const float gm = gamma ? gamma[c] : 1.f;
+      a += gm * S1; b += gm * gxh;
+      if (sl == 0 && dgb != nullptr) { dgb[(long)n * 2 * C + c] = gxh; dgb[(long)n * 2 * C + C + c] = S1; }
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { red[wv * 2] = a; red[wv * 2 + 1] = b; }       // (red is free again: the partial rows went out above)
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; w++) { LA += red[w * 2]; LB += red[w * 2 + 1]; }
+  }
   for (int c = tid; c < Cp; c += NT) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f;
     if (c < C) {
@@ -838,18 +859,25 @@ __global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __res
       const float m = mean[i], r = rstd[i];
       const float S1 = tot[2 * c], S2 = tot[2 * c + 1];
       const float gxh = r * (S2 - m * S1);
-      float a = 1.f;
-      if (mode == MT_NORM_ADAIN) {
-        a = 1.f + gb[(long)n * 2 * C + c];
-        if (sl == 0) {
-          dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
-          dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
+      if (mode == MT_NORM_LAYER) {
+        const float cnt = (float)C * (float)HW;
+        k1 = r * (gamma ? gamma[c] : 1.f);
+        k3 = -r * r * LB / cnt;
+        k2 = -r * LA / cnt - k3 * m;
+      } else {
+        float a = 1.f;
+        if (mode == MT_NORM_ADAIN) {
+          a = 1.f + gb[(long)n * 2 * C + c];
+          if (sl == 0) {
+            dgb[(long)n * 2 * C + c] = gxh;      // d(weight) = sum g*xh
+            dgb[(long)n * 2 * C + C + c] = S1;   // d(bias)   = sum g
+          }
         }
+        const float hw = (float)HW;
+        k1 = r * a;
+        k3 = -r * a * r * gxh / hw;
+        k2 = -r * a * S1 / hw - k3 * m;
       }
-      const float hw = (float)HW;
-      k1 = r * a;
-      k3 = -r * a * r * gxh / hw;
-      k2 = -r * a * S1 / hw - k3 * m;
     }
     kf[c] = k1; kf[Cp + c] = k2; kf[2 * Cp + c] = k3;
   }
@@ -909,7 +937,7 @@ extern "C" int mt_norm_bwd_onepass_capacity(void) {
   return cap[dev];
 }
 static int onepass_geometry(int dtype, int mode, int N, int HW, int Cp, int act, long* S_out) {
-  if (dtype != MT_BF16 || !(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN) || N <= 0 || HW <= 0 || Cp < 8 || Cp % 8) return 0;
+  if (dtype != MT_BF16 || !(mode == MT_NORM_INSTANCE || mode == MT_NORM_ADAIN || mode == MT_NORM_LAYER) || N <= 0 || HW <= 0 || Cp < 8 || Cp % 8) return 0;
   const int cchunks = Cp / 8;
   if ((cchunks & (cchunks - 1)) != 0 || cchunks < 8 || cchunks > 256) return 0;
   if (!(act == MT_ACT_NONE || act == MT_ACT_RELU || act == MT_ACT_LRELU)) return 0;
@@ -931,15 +959,17 @@ extern "C" int mt_norm_bwd_onepass_ok(int dtype, int mode, int N, int HW, int Cp
   return 1;
 }
 extern "C" int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const void* x, const float* scale, const float* shift,
-                                   const float* mean, const float* rstd, const float* gb, float* dgb, void* dx, float* part,
-                                   unsigned* sync, unsigned* status, int spin_limit, int N, int HW, int C, int Cp, int act,
-                                   float slope, mt_stream_t st) {
+                                   const float* mean, const float* rstd, const float* gb, float* dgb, const float* gamma,
+                                   float* dgamma, float* dbeta, void* dx, float* part, unsigned* sync, unsigned* status,
+                                   int spin_limit, int N, int HW, int C, int Cp, int act, float slope, mt_stream_t st) {
   long S = 0;
   MT_CHECK(onepass_geometry(dtype, mode, N, HW, Cp, act, &S), "norm_bwd_onepass: unsupported problem (dtype %d mode %d HW %d Cp %d act %d)",
            dtype, mode, HW, Cp, act);
   MT_CHECK(S <= mt_norm_bwd_onepass_capacity(), "norm_bwd_onepass: %ld slices per image exceed the %d workgroups that can be resident",
            S, mt_norm_bwd_onepass_capacity());
   MT_CHECK(mode != MT_NORM_ADAIN || (gb != nullptr && dgb != nullptr), "norm_bwd_onepass: adain needs gb/dgb");
+  MT_CHECK(mode != MT_NORM_LAYER || ((dgamma == nullptr && dbeta == nullptr) || dgb != nullptr),
+           "norm_bwd_onepass: layer norm with affine gradients needs the [N][2][C] scratch in dgb");
   MT_CHECK(part != nullptr && sync != nullptr && status != nullptr, "norm_bwd_onepass: needs the part / sync / status workspaces");
   MT_CHECK(C <= Cp && C > Cp - 8, "norm_bwd_onepass: C %d does not pad to Cp %d", C, Cp);
   if (spin_limit <= 0) spin_limit = MT_OP_SPIN;
@@ -948,7 +978,7 @@ extern "C" int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const vo
 #define MT_ONEPASS(CC)                                                                                                       \
   case CC:                                                                                                                   \
     hipLaunchKernelGGL((norm_bwd_onepass_kernel<CC, MT_OP_NT, MT_OP_PAIRS>), dim3(N * (int)S), dim3(MT_OP_NT), 0, s, (const u32x4*)dy, (const u32x4*)x, scale, \
-                       shift, mean, rstd, gb, dgb, (u32x4*)dx, part, sync, status, spin_limit, N, HW, C, (int)S, mode, act, slope); \
+                       shift, mean, rstd, gb, dgb, gamma, (u32x4*)dx, part, sync, status, spin_limit, N, HW, C, (int)S, mode, act, slope); \
     break
   switch (cchunks) {
     MT_ONEPASS(8); MT_ONEPASS(16); MT_ONEPASS(32); MT_ONEPASS(64); MT_ONEPASS(128); MT_ONEPASS(256);
@@ -956,6 +986,10 @@ extern "C" int mt_norm_bwd_onepass(int dtype, int mode, const void* dy, const vo
   }
 #undef MT_ONEPASS
   MT_LAUNCH_CHECK();
+  if (mode == MT_NORM_LAYER && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, dgb, dgamma, dbeta, N, C);
+    MT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

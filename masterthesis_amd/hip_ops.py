@@ -1213,13 +1213,23 @@ class _Norm(torch.autograd.Function):
             if sl is not None:
                 sl.sums = None
             dgb = torch.empty_like(gbc) if mode == L.NORM_ADAIN else None
+            dgamma = dbeta = None
+            if mode == L.NORM_LAYER and gm is not None:
+                dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
+                dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+                dgb = torch.empty((N, 2, Cc), dtype=torch.float32, device=dev)          # per-image terms of dgamma / dbeta
             dx = new_act(N, Cc, H, W, x.dtype, dev)
             part = torch.empty((N, nsl, Cp, 2), dtype=torch.float32, device=dev)
             with _hbm("norm_bwd_onepass", N * HW * Cp * x.element_size() * 3):
                 L.check(lib.mt_norm_bwd_onepass(mt, mode, _ptr(dy), _ptr(x), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]),
-                                                _ptr(coef[3]), _ptr(gbc), _ptr(dgb), _ptr(dx), _ptr(part), _ptr(sync),
-                                                _ptr(status), _ONEPASS_SPIN[0], N, HW, Cc, Cp, act, slope, _stream()),
-                        "mt_norm_bwd_onepass")
+                                                _ptr(coef[3]), _ptr(gbc), _ptr(dgb), _ptr(gm), _ptr(dgamma), _ptr(dbeta),
+                                                _ptr(dx), _ptr(part), _ptr(sync), _ptr(status), _ONEPASS_SPIN[0], N, HW, Cc,
+                                                Cp, act, slope, _stream()), "mt_norm_bwd_onepass")
+            if mode == L.NORM_LAYER:
+                gshape, bshape = ctx.shapes
+                if dgamma is not None:
+                    dgamma, dbeta = dgamma.view(gshape), dbeta.view(bshape)
+                return dx, None, dgamma, dbeta, None, None, None
             dres = dy if ctx.needs_input_grad[4] else None
             link = ctx.cfg[5] if len(ctx.cfg) > 5 else None
             if link is not None and dres is not None:

@@ -25,12 +25,19 @@ pytestmark = pytest.mark.gpu
 
 RES, DOMAINS = 256, 4
 # tools/oracle_fullwidth_noise.py (fp32 oracle vs fp64 oracle, batch_size 1, this size), rel-L2 per optimizer step:
-# D1, D2 | Ec, Es, Dec (phase 3) | Ec, Dec (phase 4)  -- filled in from gpurun_out/oracle_noise_256.log
-FP32_ORACLE_NOISE = [None] * 7
+# D1, D2 | Ec, Es, Dec (phase 3) | Ec, Dec (phase 4); all 13 loss scalars agree to < 2e-7.  The phase-4 content-encoder gradient is
+# cancellation-dominated at FULL width too (cos 0.9951 between the two oracles): the 0.25 bound of the narrow fixtures was not a
+# width artefact, and no fp32 implementation can be pinned closer than this to another fp32 one there.
+FP32_ORACLE_NOISE = [1.3e-5, 1.7e-5, 3.9e-3, 5.7e-4, 1.0e-3, 9.9e-2, 9.5e-3]
 # fp32 product vs fp32 oracle: rel-L2 per optimizer step
-FP32_TOL = [5e-3, 5e-3, 3e-2, 3e-2, 3e-2, 5e-2, 5e-2]
+# measured (round 4, MI355X): b1 2.1e-4 / 7.0e-5 | 1.2e-2 / 2.1e-3 / 6.9e-3 | 0.128 / 1.3e-2; b4 2.7e-4 / 3.4e-4 | 8.5e-3 / 2.6e-4 / 1.4e-3 |
+# 0.119 / 6.1e-3; with the fallback paths 2.8e-5 / 5.8e-5 | 6.3e-3 / 1.8e-3 / 1.6e-3 | 0.110 / 1.0e-2 -- i.e. 1.2-3x the fp32 oracle's own
+# distance from fp64 in the generator phases
+FP32_TOL = [2e-3, 2e-3, 3e-2, 1e-2, 2e-2, 0.3, 4e-2]
 # bf16 product vs fp32 oracle: (cosine lower bound, norm-ratio window) per optimizer step
-BF16_DIR = [(0.95, (0.9, 1.1))] * 2 + [(0.9, (0.85, 1.2))] * 3 + [(0.8, (0.75, 1.3))] * 2
+# measured: D phases cos 0.9992-0.9997; phase 3 content encoder cos 0.895-0.900, ratio 0.997-0.999 (the L1 terms and ReLU masks make
+# the gradient piecewise constant in the bf16 forward activations: tests/test_step_gpu.py)
+BF16_DIR = [(0.99, (0.95, 1.05))] * 2 + [(0.8, (0.85, 1.25))] * 3 + [(0.5, (0.6, 1.5))] * 2
 STEP_NETS = ["discriminator1", "discriminator2", "content_encoder", "style_encoder", "decoder", "content_encoder", "decoder"]
 
 _ORACLE = {}
@@ -115,6 +122,7 @@ def test_fullwidth_step_matches_oracle(batch_size, precision, fallbacks, tmp_pat
         assert abs(got[k] - v) <= loss_tol * max(abs(v), 1e-2), f"b{batch_size}/{precision} loss {k}: {got[k]} vs oracle {v}"
     assert [n for n, _ in seen] == STEP_NETS
     diag = os.environ.get("MT_STEP_DIAG")
+    bad = []
     for j, ((net, g), (_, tg)) in enumerate(zip(seen, t_grads)):
         assert set(tg) <= set(g), (net, set(tg) - set(g))
         ours, ref = _vec(g, tg), _vec(tg, tg)
@@ -126,10 +134,13 @@ def test_fullwidth_step_matches_oracle(batch_size, precision, fallbacks, tmp_pat
             print(f"DIAG fullwidth b{batch_size} {precision}{' fallbacks' if fallbacks else ''} step{j} {net}: rel {rel:.3e} "
                   f"cos {cos:.5f} ratio {ratio:.4f}")
         if precision == "fp32":
-            assert rel <= FP32_TOL[j], f"b{batch_size}/fp32 step {j} {net}: gradient rel-L2 {rel:.3e} vs the fp32 oracle"
+            if rel > FP32_TOL[j]:
+                bad.append(f"b{batch_size}/fp32 step {j} {net}: gradient rel-L2 {rel:.3e} vs the fp32 oracle (bound {FP32_TOL[j]})")
         else:
             cmin, (lo, hi) = BF16_DIR[j]
-            assert cos >= cmin and lo <= ratio <= hi, f"b{batch_size}/bf16 step {j} {net}: cos {cos:.4f} ratio {ratio:.4f}"
+            if not (cos >= cmin and lo <= ratio <= hi):
+                bad.append(f"b{batch_size}/bf16 step {j} {net}: cos {cos:.4f} ratio {ratio:.4f}")
+    assert not bad, "; ".join(bad)
     # the run really went through the paths this test exists for (or, with fallbacks, around them)
     kinds = {}
     for kind, d, _ms in log:
@@ -142,7 +153,6 @@ def test_fullwidth_step_matches_oracle(batch_size, precision, fallbacks, tmp_pat
     else:
         assert merged, "the multi-scale discriminators did not take the merged mini-image path"
         assert "wgrad_sum" in kinds, "no weight shared one slab sum across its uses"
-        if batch_size >= 4:
+        if batch_size >= 4 and precision == "bf16":      # (the 256x256 weight-gradient kernel and the one-pass backward are bf16 kernels)
             assert grouped, "no grouped weight-gradient launch at batch_size 4"
-            if precision == "bf16":
-                assert "norm_bwd_onepass" in used
+            assert "norm_bwd_onepass" in used

@@ -142,7 +142,7 @@ def test_give_up_reaches_the_host(hip_device):
     status = torch.zeros(4, dtype=torch.int32, device=hip_device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.check(lib.mt_norm_bwd_onepass(L.MT_BF16, L.NORM_INSTANCE, P(dy), P(x), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), None,
-                                    None, P(dx), P(part), P(sync), P(status), 64, N, H * W, Cc, Cc, L.ACT_RELU, 0.0, st), "onepass")
+                                    None, None, None, None, P(dx), P(part), P(sync), P(status), 64, N, H * W, Cc, Cc, L.ACT_RELU, 0.0, st), "onepass")
     torch.cuda.synchronize()
     words = status.cpu().tolist()
     assert words[0] & 1 and 3 * S < words[1] <= 4 * S, words          # a workgroup of image 3 reported
@@ -178,4 +178,59 @@ def test_launches_from_two_streams_are_ordered(hip_device):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, ref)
+    ops.check_device_status(hip_device)
+
+
+LN_CASES = [
+    ("ln_relu_128ch_128", 4, 128, 128, 128, "relu"),        # dec2.0 (reference networks.py:248-249): 32 slices per image
+    ("ln_relu_64ch_256", 2, 64, 256, 256, "relu"),          # dec2.1: 64 slices per image
+    ("ln_none_256ch_64", 8, 256, 64, 64, None),
+]
+
+
+@pytest.mark.parametrize("case", LN_CASES, ids=[c[0] for c in LN_CASES])
+def test_onepass_layer_norm_matches_three_pass_and_reference(case, hip_device):
+    """Round 4: the reference's per-sample LayerNorm (norm.py:5-21; its backward was the reference's CPU outlier) on the one-pass
+    kernel: dx, dgamma, dbeta against the three-launch backward on the same device tensors and against the fp32 CPU reference."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    name, N, C, H, W, act = case
+    x0 = (_rnd(N, C, H, W, seed=1) * 1.5 + 0.3)
+    g0 = _rnd(C, 1, 1, seed=2, scale=0.5) + 1.0
+    b0 = _rnd(C, 1, 1, seed=3, scale=0.2)
+    gy = _rnd(N, C, H, W, seed=4)
+    outs = {}
+    for onepass in (True, False):
+        ops.set_norm_onepass(onepass)
+        try:
+            x = x0.to(hip_device).requires_grad_()
+            gm = g0.to(hip_device).requires_grad_()
+            bt = b0.to(hip_device).requires_grad_()
+            ops.hbm_timer_start()
+            y = ops.layer_norm_act(x, gm, bt, act=act)
+            y.backward(gy.to(hip_device))
+            torch.cuda.synchronize()
+            used = ops.hbm_timer_stop()
+            outs[onepass] = (y.detach(), x.grad.float().cpu(), gm.grad.cpu(), bt.grad.cpu(), used)
+        finally:
+            ops.set_norm_onepass(True)
+    y1, dx1, dg1, db1, used1 = outs[True]
+    y3, dx3, dg3, db3, used3 = outs[False]
+    assert "norm_bwd_onepass" in used1 and "norm_bwd_onepass" not in used3 and "norm_bwd_apply" in used3
+    assert torch.equal(y1, y3)
+    d = (dx1 - dx3).abs()
+    ref = dx3.abs().max().item()
+    assert d.max().item() <= 2 ** -7 * ref + 1e-6 and (d > 0).float().mean().item() < 0.02, (name, d.max().item(), ref)
+    assert torch.allclose(dg1, dg3, rtol=2e-4, atol=2e-4 * dg3.abs().max().item())
+    assert torch.allclose(db1, db3, rtol=2e-4, atol=2e-4 * db3.abs().max().item())
+    xr, gr, br = x0.clone().requires_grad_(), g0.clone().requires_grad_(), b0.clone().requires_grad_()
+    shp = xr.shape[1:]
+    yr = F.layer_norm(xr, shp, gr.expand(shp), br.expand(shp))
+    if act == "relu":
+        yr = F.relu(yr)
+    yr.backward(gy)
+    assert ((dx1 - xr.grad).norm() / xr.grad.norm()).item() <= 4e-2
+    # (bf16 x / dy / dx storage: 2.1e-2 measured on dbeta of the 64-channel case, the three-launch backward gives the same value)
+    assert ((dg1 - gr.grad).norm() / gr.grad.norm()).item() <= 4e-2
+    assert ((db1 - br.grad).norm() / br.grad.norm()).item() <= 4e-2
     ops.check_device_status(hip_device)

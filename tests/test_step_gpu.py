@@ -162,7 +162,7 @@ def test_training_step_matches_reference(name, precision, tmp_path, hip_device):
                 ratio = (ours_v.norm() / (ref_v.norm() + 1e-300)).item()
                 if os.environ.get("MT_STEP_DIAG"):
                     print(f"DIAG {name} {precision} it{it} step{j} {net}: rel {net_rel:.3e} cos {cos:.4f} ratio {ratio:.3f}")
-                    if os.environ.get("MT_STEP_DIAG") == "2" and j >= 5:
+                    if os.environ.get("MT_STEP_DIAG") == "2" and j >= int(os.environ.get("MT_STEP_DIAG_FROM", "5")):
                         for k, ref in tg.items():
                             print(f"   DIAG2 {net}.{k}: |ours| {g[k].double().norm().item():.3e} |ref| {ref.norm().item():.3e} "
                                   f"rel {_rel(g[k], ref):.3e}")

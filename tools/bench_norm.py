@@ -71,7 +71,7 @@ for (N, Cc, H, W, act, res) in [(16, 256, 64, 64, L.ACT_RELU, False), (16, 256, 
         sync = torch.zeros(2 * N, dtype=torch.int32, device=dev)
         status = torch.zeros(4, dtype=torch.int32, device=dev)
         t_op = timeit(lambda: lib.mt_norm_bwd_onepass(L.MT_BF16, L.NORM_INSTANCE, P(dy), P(x), P(coef[0]), P(coef[1]), P(coef[2]),
-                                                      P(coef[3]), None, None, P(y), P(part1), P(sync), P(status), 0, N, HW, Cc, Cp, act, 0.01,
+                                                      P(coef[3]), None, None, None, None, None, P(y), P(part1), P(sync), P(status), 0, N, HW, Cc, Cp, act, 0.01,
                                                       st()))
         assert int(sync.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
     print(f"   one-pass backward {t_op:.1f}us ({tbs(3 * nbytes, t_op):.2f} TB/s) vs three-pass {t_sb + t_fb + t_ab:.1f}us")

@@ -20,6 +20,7 @@ SHAPES = [
     ("Ec down 3x3s2 64->128 @256 N16", "conv", 16, 64, 256, 256, 128, 2, "reflect"),
     ("Es 3x3s1 64->64 @128 N16", "conv", 16, 64, 128, 128, 64, 1, "reflect"),
     ("Es 3x3s1 64->128 @128 N16", "conv", 16, 64, 128, 128, 128, 1, "reflect"),
+    ("Es 3x3s1 128->128 @64 N16", "conv", 16, 128, 64, 64, 128, 1, "reflect"),
     ("Dec convT 128->64 @128 N16", "convT", 16, 128, 128, 128, 64, 2, "zero"),
     ("Dec convT 128->64 @128 N32", "convT", 32, 128, 128, 128, 64, 2, "zero"),
 ]
