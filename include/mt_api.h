@@ -321,6 +321,11 @@ int mt_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, 
  * pixel sums the at most four patch cells that copied it).  H, W even. */
 int mt_patch4s2_fwd(int dtype, const void* x, void* col, int N, int H, int W, int Cp, mt_stream_t s);
 int mt_patch4s2_bwd(int dtype, const void* dcol, void* dx, int N, int H, int W, int Cp, mt_stream_t s);
+/* the same for up to four inputs of equal channel count in ONE launch (the weight-shared scales of a multi-scale discriminator
+ * layer): bwd = 0: src[k] = input k, dst[k] = its slice of the mini-image batch; bwd = 1: src[k] = the slice of the batch's
+ * gradient, dst[k] = the gradient of input k (null: not needed). */
+int mt_patch4s2_multi(int dtype, int bwd, int count, const void* const* src, void* const* dst, const int* N, const int* H,
+                      const int* W, int Cp, mt_stream_t s);
 /* AdaptiveAvgPool2d(1): y fp32 [N][C] (logical channels). */
 int mt_gap_fwd(int dtype, const void* x, float* y, int N, int HW, int C, int Cp, mt_stream_t s);
 int mt_gap_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, int Cp, mt_stream_t s);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mt_avgpool3s2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_patch4s2_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_patch4s2_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "mt_patch4s2_multi": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "mt_gap_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_gap_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
     "mt_to_nhwc": (_i, [_i, _p, _i64, _i64, _i64, _i64, _i, _p, _i, _i, _i, _i, _p]),

@@ -468,6 +468,95 @@ extern "C" int mt_patch4s2_bwd(int dtype, const void* dcol, void* dx, int N, int
   return launch_patch4s2<true>(dtype, dcol, dx, N, H, W, Cp, (hipStream_t)s);
 }
 
+// ---- the same for up to four inputs in ONE launch (round 4): the scales of a multi-scale discriminator layer (networks.py:445-466)
+// were three launches of ~6 us each way, 72 per step; the tensors are tiny next to a launch's fixed cost
+struct Patch4Multi {
+  const u32x4* src[4];
+  u32x4* dst[4];
+  int N[4], H[4], W[4];
+  long end[4];        // cumulative work items (16-byte chunks) up to and including input k
+  int count;
+};
+template <bool BF16, bool BWD>
+__global__ void patch4s2_multi_kernel(const Patch4Multi m, int cchunks) {
+  constexpr int V = Elem<BF16>::V;
+  const long total = m.end[m.count - 1];
+  for (long gi = blockIdx.x * (long)blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) k = (j + 1 < m.count && gi >= m.end[j]) ? j + 1 : k;
+    const long i = gi - (k ? m.end[k - 1] : 0);
+    const int H = m.H[k], W = m.W[k], Ho = H >> 1, Wo = W >> 1;
+    const u32x4* __restrict__ src = m.src[k];
+    u32x4* __restrict__ dst = m.dst[k];
+    const int cq = (int)(i % cchunks);
+    long t = i / cchunks;
+    if constexpr (!BWD) {
+      const int b = (int)(t & 3), a = (int)((t >> 2) & 3);
+      t >>= 4;
+      const int wo = (int)(t % Wo); t /= Wo;
+      const int ho = (int)(t % Ho);
+      const int n = (int)(t / Ho);
+      const int h = 2 * ho - 1 + a, w = 2 * wo - 1 + b;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = src[(((long)n * H + h) * W + w) * cchunks + cq];
+      dst[i] = v;
+    } else {
+      const int w = (int)(t % W); t /= W;
+      const int h = (int)(t % H);
+      const int n = (int)(t / H);
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; e++) acc[e] = 0.f;
+#pragma unroll
+      for (int ia = 0; ia < 2; ia++) {
+        const int a = ((h + 1) & 1) + 2 * ia, ho = (h + 1 - a) >> 1;
+        if ((unsigned)ho >= (unsigned)Ho) continue;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+          const int b = ((w + 1) & 1) + 2 * ib, wo = (w + 1 - b) >> 1;
+          if ((unsigned)wo >= (unsigned)Wo) continue;
+          float f[V];
+          Elem<BF16>::unpack(src[((((long)n * Ho + ho) * Wo + wo) * 16 + a * 4 + b) * cchunks + cq], f);
+#pragma unroll
+          for (int e = 0; e < V; e++) acc[e] += f[e];
+        }
+      }
+      dst[i] = Elem<BF16>::pack(acc);
+    }
+  }
+}
+// count <= 4 inputs [N_k][H_k][W_k][Cp]; fwd: src = the inputs, dst = their slices of the mini-image batch; bwd: src = the slices of
+// the batch's gradient, dst = the input gradients (a null dst: that input needs no gradient)
+extern "C" int mt_patch4s2_multi(int dtype, int bwd, int count, const void* const* src, void* const* dst, const int* N, const int* H,
+                                 const int* W, int Cp, mt_stream_t st) {
+  MT_CHECK(count >= 1 && count <= 4 && Cp % 8 == 0, "patch4s2_multi: %d inputs, Cp %d", count, Cp);
+  const int V = dtype == MT_BF16 ? 8 : 4;
+  Patch4Multi m;
+  long tot = 0;
+  for (int k = 0; k < count; k++) {
+    MT_CHECK(N[k] > 0 && H[k] >= 2 && W[k] >= 2 && H[k] % 2 == 0 && W[k] % 2 == 0, "patch4s2_multi: input %d is %d x %d x %d", k, N[k], H[k], W[k]);
+    m.src[k] = (const u32x4*)src[k]; m.dst[k] = (u32x4*)dst[k]; m.N[k] = N[k]; m.H[k] = H[k]; m.W[k] = W[k];
+    const long items = dst[k] == nullptr ? 0 : (bwd ? (long)N[k] * H[k] * W[k] : (long)N[k] * (H[k] / 2) * (W[k] / 2) * 16) * (Cp / V);
+    tot += items;
+    m.end[k] = tot;
+  }
+  for (int k = count; k < 4; k++) { m.src[k] = nullptr; m.dst[k] = nullptr; m.N[k] = m.H[k] = m.W[k] = 2; m.end[k] = tot; }
+  m.count = count;
+  if (tot == 0) return 0;
+  const int blocks = (int)min((long)8192, (tot + 255) / 256);
+  hipStream_t s = (hipStream_t)st;
+  if (dtype == MT_BF16) {
+    if (bwd) hipLaunchKernelGGL((patch4s2_multi_kernel<true, true>), dim3(blocks), dim3(256), 0, s, m, Cp / V);
+    else hipLaunchKernelGGL((patch4s2_multi_kernel<true, false>), dim3(blocks), dim3(256), 0, s, m, Cp / V);
+  } else {
+    if (bwd) hipLaunchKernelGGL((patch4s2_multi_kernel<false, true>), dim3(blocks), dim3(256), 0, s, m, Cp / V);
+    else hipLaunchKernelGGL((patch4s2_multi_kernel<false, false>), dim3(blocks), dim3(256), 0, s, m, Cp / V);
+  }
+  MT_LAUNCH_CHECK();
+  return 0;
+}
+
 // AdaptiveAvgPool2d(1): one block per (n, channel slab); fp32 output [N][C]
 template <bool BF16>
 __global__ void gap_fwd_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int HW, int cchunks, int C) {

@@ -1506,11 +1506,19 @@ class _Patch4s2Multi(torch.autograd.Function):
         counts = [x.shape[0] * (x.shape[2] // 2) * (x.shape[3] // 2) for x in xs]
         col = new_act(sum(counts), Cc, 4, 4, dt, dev)
         row = 16 * padc(Cc) * col.element_size()
-        off = 0
-        for x, n in zip(xs, counts):
-            L.check(lib.mt_patch4s2_fwd(_mt(dt), _ptr(x), C.c_void_p(col.data_ptr() + off * row), x.shape[0], x.shape[2],
-                                        x.shape[3], padc(Cc), _stream()), "mt_patch4s2_fwd")
+        offs, off = [], 0
+        for n in counts:
+            offs.append(off)
             off += n
+        for k in range(0, len(xs), 4):              # (one launch per group of up to four inputs: the scales of a layer)
+            grp = list(range(k, min(k + 4, len(xs))))
+            G = len(grp)
+            src = (C.c_void_p * G)(*[xs[i].data_ptr() for i in grp])
+            dst = (C.c_void_p * G)(*[col.data_ptr() + offs[i] * row for i in grp])
+            Ns = (C.c_int * G)(*[xs[i].shape[0] for i in grp])
+            Hs = (C.c_int * G)(*[xs[i].shape[2] for i in grp])
+            Ws = (C.c_int * G)(*[xs[i].shape[3] for i in grp])
+            L.check(lib.mt_patch4s2_multi(_mt(dt), 0, G, src, dst, Ns, Hs, Ws, padc(Cc), _stream()), "mt_patch4s2_multi")
         ctx.shapes = [tuple(x.shape) for x in xs]
         ctx.counts = counts
         return col
@@ -1521,15 +1529,20 @@ class _Patch4s2Multi(torch.autograd.Function):
         dcol = canon(dcol)
         Cc = dcol.shape[1]
         row = 16 * padc(Cc) * dcol.element_size()
-        outs, off = [], 0
+        outs, offs, off = [], [], 0
         for (N, _, H, W), n, need in zip(ctx.shapes, ctx.counts, ctx.needs_input_grad):
-            dx = None
-            if need:
-                dx = new_act(N, Cc, H, W, dcol.dtype, dcol.device)
-                L.check(lib.mt_patch4s2_bwd(_mt(dcol.dtype), C.c_void_p(dcol.data_ptr() + off * row), _ptr(dx), N, H, W,
-                                            padc(Cc), _stream()), "mt_patch4s2_bwd")
-            outs.append(dx)
+            outs.append(new_act(N, Cc, H, W, dcol.dtype, dcol.device) if need else None)
+            offs.append(off)
             off += n
+        for k in range(0, len(outs), 4):
+            grp = list(range(k, min(k + 4, len(outs))))
+            G = len(grp)
+            src = (C.c_void_p * G)(*[dcol.data_ptr() + offs[i] * row for i in grp])
+            dst = (C.c_void_p * G)(*[None if outs[i] is None else outs[i].data_ptr() for i in grp])
+            Ns = (C.c_int * G)(*[ctx.shapes[i][0] for i in grp])
+            Hs = (C.c_int * G)(*[ctx.shapes[i][2] for i in grp])
+            Ws = (C.c_int * G)(*[ctx.shapes[i][3] for i in grp])
+            L.check(lib.mt_patch4s2_multi(_mt(dcol.dtype), 1, G, src, dst, Ns, Hs, Ws, padc(Cc), _stream()), "mt_patch4s2_multi")
         return tuple(outs)
 
 

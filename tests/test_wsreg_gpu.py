@@ -20,7 +20,7 @@ CASES = [
     ("g_s2_64_128_reflect", "conv", 4, 64, 256, 256, 128, 3, 2, 1, "reflect", True, "relu", (1, 1)),       # dgrad: scatter 128 -> 64
     ("g_s1_64_64_zero_ragged", "conv", 8, 64, 100, 120, 64, 3, 1, 1, "zero", False, None, (1, None)),
     ("g_s2_64_128_zero_odd", "conv", 6, 64, 135, 241, 128, 3, 2, 1, "zero", True, None, (1, 1)),
-    ("g_s1_128_128_reflect", "conv", 16, 128, 64, 64, 128, 3, 1, 1, "reflect", True, "lrelu", (1, None)),  # 8 waves x 16 channels
+    ("g_s1_128_128_not_taken", "conv", 16, 128, 64, 64, 128, 3, 1, 1, "reflect", True, "lrelu", (0, None)),  # (8 x 16 channels: no gain)
     ("g_s1_128_64_zero", "conv", 8, 128, 96, 96, 64, 3, 1, 1, "zero", False, None, (1, None)),
     ("s_convT_128_64", "convT", 4, 128, 128, 128, 64, 3, 2, 1, "zero", True, None, (1, 1)),                # dgrad: gather s2 64 -> 128
     ("s_convT_128_64_odd_relu", "convT", 2, 128, 135, 240, 64, 3, 2, 1, "zero", True, "relu", (1, 1)),      # dec2.1 at 540 x 960

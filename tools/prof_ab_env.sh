@@ -8,7 +8,7 @@ i=0
 for v in "$1" "$2"; do
   rm -rf $R/gpurun_out/pab_$i
   # (a subshell per arm: the setting of one arm must not leak into the other)
-  ( export $v; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pab_$i -o p -- python3 $R/bench.py --no_cpu_baseline --no_extra --no_hbm_kernels --steps 6 --warmup 3 $3 > $R/gpurun_out/pab_$i.log 2>&1 )
+  ( export $v; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pab_$i -o p -- python3 $R/bench.py --eager --no_cpu_baseline --no_extra --no_hbm_kernels --steps 6 --warmup 3 $3 > $R/gpurun_out/pab_$i.log 2>&1 )
   python3 $R/tools/rocpd_stats.py $(find $R/gpurun_out/pab_$i -name "*.db" | head -1) 400 > $R/gpurun_out/pab_$i.txt
   i=$((i+1))
 done

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in ss ms; do
   rm -rf $R/gpurun_out/prof_${VER}_$v
   flag=""; [ $v = ss ] && flag="--single_scale"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${VER}_$v -o ${VER} -- python3 $R/bench.py --no_cpu_baseline --no_extra --no_hbm_kernels --steps 6 --warmup 3 $flag > $R/gpurun_out/prof_${VER}_$v.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${VER}_$v -o ${VER} -- python3 $R/bench.py --eager --no_cpu_baseline --no_extra --no_hbm_kernels --steps 6 --warmup 3 $flag > $R/gpurun_out/prof_${VER}_$v.log 2>&1
   DB=$(find $R/gpurun_out/prof_${VER}_$v -name "*.db" | head -1)
   python3 $R/tools/rocpd_stats.py $DB 80 > $R/gpurun_out/${VER}_${v}_kernel_stats.txt
   python3 $R/tools/rocpd_stats.py $DB 120 grid > $R/gpurun_out/${VER}_${v}_kernel_stats_by_grid.txt
