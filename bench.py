@@ -364,8 +364,8 @@ def main():
     # rocprofv3 PMC passes of this exact shape (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md; collected
     # with tools/pmc_k1.sh) and labelled as such
     traffic, mfma_busy, pmc_src, pmc_commit, pmc_kernel = None, None, None, None, None
-    for cand in ("round3_k1_fwd_pmc.json",):
-        # (only a PMC file collected on THIS round's kernel is cited: the round-2 file describes the ring kernel)
+    for cand in ("round4_k1_fwd_pmc.json",):
+        # (only a PMC file collected on THIS round's binary is cited, with its commit inside)
         pmc_path = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(pmc_path) and o.precision == "bf16" and o.batch_size == 8 and o.crop_size == 256:
             with open(pmc_path) as f:

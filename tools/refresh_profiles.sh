@@ -2,8 +2,8 @@
 # -> gpurun_out/{bench_default.json, <ver>_kernel_stats*.txt, layer_table*.txt}, profiles/<round>_k1_*_pmc.json
 set -e
 R=$(pwd)
-ROUND=${1:-round3}
-VER=${2:-v11}
+ROUND=${1:-round4}
+VER=${2:-v17}
 echo "== bench default (driver-style: no flags)"
 timeout -k 10 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.json; echo
 echo "== kernel stats (single-scale, the headline of rounds 1-2, and the multi-scale headline)"
@@ -26,3 +26,13 @@ echo "== PMC passes of the K1 trio"
 bash tools/pmc_k1.sh $ROUND > gpurun_out/pmc_k1.log 2>&1 || tail -5 gpurun_out/pmc_k1.log
 ls profiles/${ROUND}_k1_*_pmc.json && cp profiles/${ROUND}_k1_*_pmc.json gpurun_out/
 rm -rf gpurun_out/pmc_*_f gpurun_out/pmc_*_w gpurun_out/pmc_*_s
+
+echo "== fabric traffic per kernel of the shipped binary (FETCH_SIZE / WRITE_SIZE passes over 3 eager steps)"
+cd /tmp && export TMPDIR=/tmp
+for pass in "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+  n=${pass%%:*}; c=${pass#*:}
+  rm -rf $R/gpurun_out/pt_$n
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pt_$n -o $n --output-format csv -- python3 $R/bench.py --eager --no_cpu_baseline --no_extra --no_hbm_kernels --steps 2 --warmup 1 > $R/gpurun_out/pt_$n.log 2>&1 || tail -3 $R/gpurun_out/pt_$n.log
+done
+cd $R && python3 tools/pmc_traffic.py gpurun_out/pt > gpurun_out/fabric_traffic_by_kernel.txt && head -5 gpurun_out/fabric_traffic_by_kernel.txt
+rm -rf gpurun_out/pt_f gpurun_out/pt_w
