@@ -165,6 +165,11 @@ int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, const void*
                                size_t ws_bytes, int accumulate, int want_dw, int* nslabs, mt_stream_t s);
 int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, int nslabs, float* dw, int accumulate,
                               mt_stream_t s);
+/* n mt_conv_bwd_weight_finish calls in as few launches as possible (the slab sums of a whole backward pass from its end: nothing
+ * reads a weight gradient before the optimizer step): entries with the generic slab form ride in batched launches of up to 64, the
+ * others run their own finish.  Same sums in the same order as n single calls. */
+int mt_conv_bwd_weight_finish_multi(int n, const mt_conv_desc* descs, const void* const* ws, const int* nslabs, float* const* dw,
+                                    int accumulate, mt_stream_t s);
 /* Size of one slab of mt_conv_bwd_weight_partial if the slabs have the generic form (it depends on the weight's shape only), else
  * 0.  Several uses of ONE weight in a backward pass (the weight-shared scales of MultiScaleDiscriminator, networks.py:330-365; an
  * encoder applied twice) may then write their slabs behind each other into one workspace -- partial(d_i, ..., ws + used slabs) --

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mt_conv_bwd_weight_group": (_i, [_dp, _i, _p, _p, _p, _p, _z, _i, _p]),
     "mt_conv_bwd_weight_partial": (_i, [_dp, _p, _p, _p, _p, _z, _i, _i, C.POINTER(C.c_int), _p]),
     "mt_conv_bwd_weight_finish": (_i, [_dp, _p, _i, _p, _i, _p]),
+    "mt_conv_bwd_weight_finish_multi": (_i, [_i, _p, _p, _p, _p, _i, _p]),
     "mt_conv_bwd_weight_slab_bytes": (_z, [_dp]),
     "mt_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -775,6 +775,42 @@ extern "C" int mt_conv_bwd_weight_finish(const mt_conv_desc* d, const void* ws, 
   return mt_launch_unpack((const float*)ws, dw, u, nslabs, slab, accumulate, (hipStream_t)st) ? 2 : 0;
 }
 
+// Several mt_conv_bwd_weight_finish calls of one backward pass in as few launches as possible (round 4): the slab sums whose
+// unpack has the natural tap order ride in batched launches of up to 64 entries, the rest (7x7 stem, thin 1x1) keep their own.
+extern "C" int mt_conv_bwd_weight_finish_multi(int n, const mt_conv_desc* descs, const void* const* ws, const int* nslabs,
+                                               float* const* dw, int accumulate, mt_stream_t st) {
+  MT_CHECK(n >= 0 && (n == 0 || (descs && ws && nslabs && dw)), "conv_bwd_weight_finish_multi: null argument");
+  hipStream_t s = (hipStream_t)st;
+  const float* src[MT_UNPACK_MULTI_MAX];
+  float* dst[MT_UNPACK_MULTI_MAX];
+  PackParams ps[MT_UNPACK_MULTI_MAX];
+  int ns[MT_UNPACK_MULTI_MAX];
+  long slabs[MT_UNPACK_MULTI_MAX];
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    const mt_conv_desc* d = &descs[i];
+    if (check_desc(d)) return 1;
+    MT_CHECK(ws[i] != nullptr && dw[i] != nullptr && nslabs[i] > 0, "conv_bwd_weight_finish_multi: entry %d has nothing to reduce", i);
+    PackParams u;
+    if (!mt_stem_wgrad_ok(d) && !mt_pointwise_small(d)) {
+      bwd_weight_unpack_params(d, &u);
+      if (mt_unpack_multi_ok(u)) {
+        src[k] = (const float*)ws[i]; dst[k] = dw[i]; ps[k] = u; ns[k] = nslabs[i];
+        slabs[k] = (long)mt_padc(d->Co) * mt_padc(d->Ci) * d->kh * d->kw;
+        if (++k == MT_UNPACK_MULTI_MAX) {
+          if (mt_launch_unpack_multi(k, src, dst, ps, ns, slabs, accumulate, s)) return 2;
+          k = 0;
+        }
+        continue;
+      }
+    }
+    const int rc = mt_conv_bwd_weight_finish(d, ws[i], nslabs[i], dw[i], accumulate, st);
+    if (rc) return rc;
+  }
+  if (k > 0 && mt_launch_unpack_multi(k, src, dst, ps, ns, slabs, accumulate, s)) return 2;
+  return 0;
+}
+
 // bytes of ONE slab of mt_conv_bwd_weight_partial when its slabs have the generic [rows][taps][channels] form, which depends on
 // the weight's shape only -- so the slabs of several uses of one weight (different N, H, W) may sit behind each other in one
 // workspace and be summed by ONE mt_conv_bwd_weight_finish; 0 for the layers with their own slab forms (7x7 stem, thin 1x1)

@@ -153,6 +153,11 @@ struct PackGroup {
 int mt_launch_pack_groups(const PackGroup* dev_groups, int ngroups, int blocks, hipStream_t s);
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s);
+#define MT_UNPACK_MULTI_MAX 64
+// batched form (weight_pack_kernels.hip): up to 64 natural-tap-order slab sums in one launch
+bool mt_unpack_multi_ok(const PackParams& p);
+int mt_launch_unpack_multi(int n, const float* const* src, float* const* dw, const PackParams* ps, const int* nsplit, const long* slab,
+                           int accumulate, hipStream_t s);
 int mt_launch_reflect_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P,
                            hipStream_t s);
 int mt_launch_ring_fold(int dtype, const void* src, void* dst, int N, int H, int W, int Cp, int P, hipStream_t s);

@@ -2,6 +2,7 @@
 // (pack, batched pack of a whole network), and the weight-gradient slabs back to the reference layout
 // (unpack: sums the pixel-split slabs, optionally accumulating into param.grad).
 #include "mt_common.h"
+#include <string.h>
 #include "conv_params.h"
 #include <type_traits>
 
@@ -268,6 +269,106 @@ __global__ __launch_bounds__(256) void unpack_t_kernel(const float* __restrict__
       out[idx] = accumulate ? out[idx] + v : v;
     }
   }
+}
+// ---- batched slab sums (round 4): the transposing slab sum of up to 64 weight tensors in ONE launch ------------------------------
+// A backward pass of the multi-scale discriminators ends ~45 small weight gradients, each followed by its own slab sum of 3-16 us
+// (91 such launches per step, 1.0 ms: mostly a launch's fixed cost).  Nothing reads a weight gradient before the optimizer step, so
+// the sums of a whole backward pass go out together from the end-of-pass callback: the entries travel in the kernel arguments
+// (48 bytes each; natural tap order only -- every convolution weight gradient), a block finds its entry by binary search over the
+// entries' first-block numbers and then is unpack_t_kernel: sums one float4 of every slab (eight in flight, index order), transposes
+// [tap][column] -> [column][tap] through LDS, leaves as contiguous float4 read-modify-writes.  Same arithmetic, same order, same
+// results as the single launches.
+struct UnpackEntry {
+  const float* src;
+  float* dw;
+  long slab;          // floats per slab
+  long sr;            // element stride of a row in dw
+  int nsplit, R, C, Cp, nt, blk0, cblocks, pad_;
+};
+struct UnpackMulti {
+  UnpackEntry e[MT_UNPACK_MULTI_MAX];
+  int n, accumulate;
+};
+__global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackMulti m) {
+  __shared__ float tile[64 * MT_MAX_TAPS + 64];
+  int lo = 0, hi = m.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= m.e[mid].blk0) lo = mid; else hi = mid - 1;
+  }
+  const UnpackEntry& en = m.e[lo];
+  const int b = (int)blockIdx.x - en.blk0;
+  const int r = b / en.cblocks, c0 = (b - r * en.cblocks) * 64, nt = en.nt, S = nt | 1;
+  const int Cp = en.Cp, nsplit = en.nsplit, accumulate = m.accumulate;
+  const int ncl = min(64, Cp - c0);
+  const float* base = en.src + ((long)r * nt) * Cp + c0;
+  const long sstep = en.slab >> 2;
+  for (int it = threadIdx.x; it < nt * 16; it += 256) {
+    const int t = it >> 4, c4 = it & 15, cl = c4 * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (cl < ncl) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(base + (long)t * Cp + cl);
+      int k = 0;
+      for (; k + 8 <= nsplit; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = q[(long)(k + i) * sstep];
+#pragma unroll
+        for (int i = 0; i < 8; i++) a += v[i];
+      }
+      for (; k < nsplit; k++) a += q[(long)k * sstep];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) tile[(cl + e) * S + t] = a[e];
+  }
+  __syncthreads();
+  const int nvalid = min(64, en.C - c0);
+  if (nvalid <= 0) return;
+  float* out = en.dw + (long)r * en.sr + (long)c0 * nt;
+  const int total = nvalid * nt;
+  if ((((size_t)out) & 15) == 0 && (total & 3) == 0) {
+    for (int i4 = threadIdx.x; i4 < (total >> 2); i4 += 256) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int idx = i4 * 4 + e, cl = idx / nt;
+        v[e] = tile[cl * S + (idx - cl * nt)];
+      }
+      f32x4* o = reinterpret_cast<f32x4*>(out) + i4;
+      *o = accumulate ? *o + v : v;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+      const int cl = idx / nt;
+      const float v = tile[cl * S + (idx - cl * nt)];
+      out[idx] = accumulate ? out[idx] + v : v;
+    }
+  }
+}
+// may this (natural-tap-order) unpack ride in a batched launch?
+bool mt_unpack_multi_ok(const PackParams& p) {
+  bool natural = (p.sc == p.ntaps) && p.ntaps >= 1 && p.ntaps <= MT_MAX_TAPS;
+  for (int t = 0; t < p.ntaps && natural; t++) natural = (p.kh[t] * p.kW + p.kw[t] == t);
+  return natural && p.R > 0 && p.Cp % 8 == 0;
+}
+// n <= MT_UNPACK_MULTI_MAX entries, every one mt_unpack_multi_ok
+int mt_launch_unpack_multi(int n, const float* const* src, float* const* dw, const PackParams* ps, const int* nsplit, const long* slab,
+                           int accumulate, hipStream_t s) {
+  if (n <= 0) return 0;
+  UnpackMulti m;
+  memset(&m, 0, sizeof(m));
+  int blocks = 0;
+  for (int i = 0; i < n; i++) {
+    UnpackEntry& e = m.e[i];
+    const PackParams& p = ps[i];
+    e.src = src[i]; e.dw = dw[i]; e.slab = slab[i]; e.sr = p.sr; e.nsplit = nsplit[i];
+    e.R = p.R; e.C = p.C; e.Cp = p.Cp; e.nt = p.ntaps; e.cblocks = cdiv(p.Cp, 64); e.blk0 = blocks;
+    blocks += p.R * e.cblocks;
+  }
+  m.n = n; m.accumulate = accumulate;
+  hipLaunchKernelGGL(unpack_multi_kernel, dim3(blocks), dim3(256), 0, s, m);
+  MT_LAUNCH_CHECK();
+  return 0;
 }
 int mt_launch_unpack(const float* src, float* dw, const PackParams& p, int nsplit, long slab, int accumulate,
                      hipStream_t s) {

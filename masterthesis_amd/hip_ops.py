@@ -707,7 +707,8 @@ class _Conv(torch.autograd.Function):
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
             if gw is not None and not need_b and (_wgrad_group_defer(ctx, desc, x, dy, gw)
-                                                  or _wgrad_share_defer(ctx, desc, x, dy, gw)):
+                                                  or _wgrad_share_defer(ctx, desc, x, dy, gw)
+                                                  or _wgrad_finish_defer(ctx, desc, x, dy, gw)):
                 return dx, None, db, None          # launched with its group (or at the end of this backward pass)
             nws = _desc_info(lib, desc)[5]
             ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
@@ -860,6 +861,58 @@ def _wgrad_share_defer(ctx, desc, x, dy, gw):
     return True
 
 
+# Batched slab sums (round 4).  The split GEMM of a weight gradient runs where autograd reaches it, its slab sum -- 91 launches of
+# 3-16 us per step, mostly a launch's fixed cost -- waits for the end of the backward pass, where ONE mt_conv_bwd_weight_finish_multi
+# per (up to 64) weights adds them into param.grad.  Only without a live gradient-ready hook (a data-parallel bucket wants its
+# gradients as early as possible).  MT_WGRAD_FINISH_BATCH=0 / set_wgrad_finish_batch(False): every slab sum behind its GEMM.
+_WGRAD_FINISH_ON = [os.environ.get("MT_WGRAD_FINISH_BATCH", "1") != "0"]
+
+
+def set_wgrad_finish_batch(on):
+    flush_wgrad_groups()
+    _WGRAD_FINISH_ON[0] = bool(on)
+
+
+def _wgrad_finish_defer(ctx, desc, x, dy, gw):
+    if not _WGRAD_FINISH_ON[0] or not _WGRAD_GROUP_ON[0] or getattr(ctx.owner, "_mt_ready_hook", None) is not None:
+        return False
+    lib = L.load()
+    skey = ("slab", _desc_key(desc), lib.mt_kernel_variant_epoch())
+    sb = _WGRAD_QUEUE["gmax"].get(skey)
+    if sb is None:
+        sb = int(lib.mt_conv_bwd_weight_slab_bytes(C.byref(desc)))
+        _WGRAD_QUEUE["gmax"][skey] = sb
+    if sb == 0 or not _wgrad_arm():
+        return False
+    nws = _desc_info(lib, desc)[5]
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+    ns = C.c_int(0)
+    with _oplog("wgrad", desc, (0,)):
+        L.check(lib.mt_conv_bwd_weight_partial(C.byref(desc), _ptr(x), _ptr(dy), None, _ptr(ws), nws, 1, 1, C.byref(ns), _stream()),
+                "mt_conv_bwd_weight_partial")
+    _WGRAD_QUEUE["pending"].setdefault(("finish",), []).append((ctx, desc, ws, ns.value, gw, _park_event()))
+    return True
+
+
+def _wgrad_finish_launch(items):
+    """the slab sums of every parked (desc, slabs, param.grad) in as few launches as the library needs"""
+    cur = torch.cuda.current_stream()
+    for it in items:
+        if it[5][0] != cur.cuda_stream:
+            cur.wait_event(it[5][1])
+            it[2].record_stream(cur)
+    lib = L.load()
+    n = len(items)
+    descs = (L.ConvDesc * n)(*[it[1] for it in items])
+    wss = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    nsl = (C.c_int * n)(*[it[3] for it in items])
+    gws = (C.c_void_p * n)(*[it[4].data_ptr() for it in items])
+    with _oplog("wgrad_sum", items[0][1], (0, n)):
+        L.check(lib.mt_conv_bwd_weight_finish_multi(n, descs, wss, nsl, gws, 1, _stream()), "mt_conv_bwd_weight_finish_multi")
+    for it in items:
+        _grad_use_done(it[0])
+
+
 def _wgrad_shared_launch(items):
     """partial GEMMs of every use into one workspace, one slab sum (items: uses of one weight, any geometry)"""
     if len(items) == 1:
@@ -893,7 +946,9 @@ def flush_wgrad_groups():
     _WGRAD_QUEUE["armed"] = None
     pend, _WGRAD_QUEUE["pending"] = _WGRAD_QUEUE["pending"], {}
     for key, items in pend.items():
-        if isinstance(key, tuple):                   # ("owner", id): uses of one weight
+        if key == ("finish",):                       # slab sums waiting for the end of the pass
+            _wgrad_finish_launch(items)
+        elif isinstance(key, tuple):                 # ("owner", id): uses of one weight
             _wgrad_shared_launch(items)
         else:
             _wgrad_group_launch(items)

@@ -154,3 +154,82 @@ def test_uses_of_one_weight_share_one_slab_sum(hip_device):
         ops.set_wgrad_group(True)
         ops.set_fused_grad_accumulation(fused_before)
         ops.set_grad_ready_hook(w, None)
+
+
+def test_batched_slab_sums_equal_single_finishes(hip_device):
+    """Round 4: mt_conv_bwd_weight_finish_multi (the slab sums of a whole backward pass in one launch per 64 weights) against
+    mt_conv_bwd_weight_finish per weight on the SAME slabs: bit-identical (same sums in the same order), accumulate on and off, for
+    the generic slab form (3x3, 4x4 stride 2, transposed, odd channel counts) and for the layers that keep their own finish (7x7
+    stem, thin 1x1) mixed into one call."""
+    from masterthesis_amd import hip_ops as ops, _lib as L
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = L.load()
+    # transposed, N, Ci, H, W, Co, k, stride, pad, pad_mode, out_pad
+    shapes = [(0, 4, 64, 32, 32, 128, 3, 1, 1, L.PAD_REFLECT, 0), (0, 8, 128, 16, 16, 256, 4, 2, 1, L.PAD_ZERO, 0),
+              (1, 4, 128, 16, 16, 64, 3, 2, 1, L.PAD_ZERO, 1), (0, 2, 24, 20, 20, 40, 3, 2, 1, L.PAD_ZERO, 0),
+              (0, 2, 3, 64, 64, 64, 7, 1, 3, L.PAD_REFLECT, 0), (1, 2, 64, 32, 32, 3, 1, 1, 0, L.PAD_ZERO, 0),
+              (0, 4, 256, 8, 8, 512, 4, 2, 1, L.PAD_ZERO, 0)]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    descs, wss, nsl, shapes_w = [], [], [], []
+    for i, (tr, N, Ci, H, W, Co, k, s_, pd, pm, op) in enumerate(shapes):
+        d = L.ConvDesc(L.MT_BF16, tr, N, H, W, Ci, Co, k, k, s_, pd, pm, op, L.ACT_NONE, 0.0)
+        ho, wo = C.c_int(), C.c_int()
+        L.check(lib.mt_conv_out_hw(C.byref(d), C.byref(ho), C.byref(wo)), "out_hw")
+        x = ops.canon(_rnd(N, Ci, H, W, seed=50 + i).to(hip_device))
+        dy = ops.canon(_rnd(N, Co, ho.value, wo.value, seed=70 + i, scale=0.5).to(hip_device))
+        nws = int(lib.mt_conv_bwd_weight_ws_bytes(C.byref(d)))
+        ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=hip_device)
+        ns = C.c_int(0)
+        L.check(lib.mt_conv_bwd_weight_partial(C.byref(d), P(x), P(dy), None, P(ws), nws, 0, 1, C.byref(ns), st), "partial")
+        assert ns.value > 0
+        descs.append(d); wss.append(ws); nsl.append(ns.value)
+        shapes_w.append((Ci, Co, k, k) if tr else (Co, Ci, k, k))
+    n = len(descs)
+    for accumulate in (0, 1):
+        single = [torch.full(sw, 0.125, dtype=torch.float32, device=hip_device) for sw in shapes_w]
+        multi = [t.clone() for t in single]
+        for d, ws, ns, dw in zip(descs, wss, nsl, single):
+            L.check(lib.mt_conv_bwd_weight_finish(C.byref(d), P(ws), ns, P(dw), accumulate, st), "finish")
+        da = (L.ConvDesc * n)(*descs)
+        wa = (C.c_void_p * n)(*[t.data_ptr() for t in wss])
+        na = (C.c_int * n)(*nsl)
+        ga = (C.c_void_p * n)(*[t.data_ptr() for t in multi])
+        L.check(lib.mt_conv_bwd_weight_finish_multi(n, da, wa, na, ga, accumulate, st), "finish_multi")
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(multi, single)):
+            assert torch.equal(a, b), (accumulate, i, (a - b).abs().max().item())
+            assert a.abs().max().item() > 0.2
+
+
+def test_slab_sums_wait_for_the_end_of_the_backward_pass(hip_device):
+    """hip_ops parks the slab sums of a backward pass and launches them from the end-of-pass callback: same param.grad as with
+    every sum behind its GEMM, and the op log shows one batched sum instead of one per layer."""
+    from masterthesis_amd import hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    ops.set_fused_grad_accumulation(True)
+    try:
+        ws = [(_rnd(32, 16, 3, 3, seed=1, scale=0.1), 1), (_rnd(48, 32, 4, 4, seed=2, scale=0.1), 2), (_rnd(64, 48, 3, 3, seed=3, scale=0.1), 1)]
+        x0 = _rnd(4, 16, 32, 32, seed=9)
+        grads = {}
+        for on in (True, False):
+            ops.set_wgrad_finish_batch(on)
+            params = [torch.nn.Parameter(w.clone().to(hip_device)) for w, _ in ws]
+            for p in params:
+                p.grad = torch.zeros_like(p)
+            h = x0.to(hip_device)
+            ops.oplog_start()
+            for p, (_, s_) in zip(params, ws):
+                h = ops.conv2d(h, p, None, stride=s_, pad=1, pad_mode="zero", act="lrelu")
+            h.float().sum().backward()
+            log = ops.oplog_stop()
+            sums = [d for k, d, _ in log if k == "wgrad_sum"]
+            assert len(sums) == (1 if on else 0), (on, len(sums))
+            if on:
+                assert sums[0][-1] == 3          # three weights in the one batched launch
+            grads[on] = [p.grad.clone() for p in params]
+        for a, b in zip(grads[True], grads[False]):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_wgrad_finish_batch(True)
+        ops.set_fused_grad_accumulation(False)
