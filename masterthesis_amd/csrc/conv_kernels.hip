@@ -285,6 +285,53 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
         yp[b] = p.y + ph.y_off + (((size_t)n * p.Hout + oh) * p.Wout + ow) * p.Co * (p.raw ? 4 : SZ);
     }
   }
+  // the straight-line epilogue (conv_device.h: epilogue_perm, round 4) for the permuted layout; tanh and outputs beyond 32-bit
+  // buffer offsets keep the general code below
+  if constexpr (PERM) {
+    const size_t ybytes = (size_t)p.N * p.Hout * p.Wout * p.Co * (p.raw ? 4 : SZ);
+    if (p.act != MT_ACT_TANH && ybytes < 0x7f000000ull) {
+      char* const ybase = p.y + ph.y_off;
+      unsigned yo[FP];
+      float vm[FP];
+#pragma unroll
+      for (int b = 0; b < FP; b++) {
+        yo[b] = yp[b] != nullptr ? (unsigned)(yp[b] - ybase) : EPI_OOB;
+        vm[b] = yp[b] != nullptr ? 1.f : 0.f;
+      }
+      const unsigned cob = (unsigned)(wt * WT + wcI * WC + fg * 8);
+      if (p.raw) {
+        epilogue_perm_raw<FC, FP>(acc, ybase, (unsigned)ybytes, yo, cob, p.Co);
+        return;
+      }
+      const bool stats_f = p.stats != nullptr;
+      float* const red_f = reinterpret_cast<float*>(&sW[0][0]);
+      if (stats_f) __syncthreads();                      // every wave is done reading the last weight tile
+      float* const red_lane = red_f + (wpI * WT + wcI * WC + fg * 8) * 2;
+      if (stats_f)
+        epilogue_perm<BF16, FC, FP, false, true, false, 0>(acc, ybase, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo,
+                                                           vm, cob, p.Co, red_lane, fr);
+      else
+        epilogue_perm<BF16, FC, FP, false, false, false, 0>(acc, ybase, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo,
+                                                            vm, cob, p.Co, red_lane, fr);
+      if (stats_f) {
+        __syncthreads();
+        const int m0 = pt * PT;
+        if (m0 < ph_M) {
+          const int n0 = m0 / HoWo;
+          for (int idx = tid; idx < WT * 2; idx += NT) {
+            const int col = idx >> 1;
+            if (wt * WT + col < p.Co) {
+              float t = 0.f;
+#pragma unroll
+              for (int w = 0; w < NWP; w++) t += red_f[(w * WT + col) * 2 + (idx & 1)];
+              atomicAdd(p.stats + ((size_t)n0 * p.Co + wt * WT + col) * 2 + (idx & 1), t);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if (p.raw) {
     // split-K partial: the fp32 accumulators go to this phase's slab; bias / activation are applied by the finish
     if constexpr (PERM) {

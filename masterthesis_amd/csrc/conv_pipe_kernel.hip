@@ -343,6 +343,26 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
   const bool do_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(&smem[0]);      // [NWP][WT][2]
   if (do_stats) __syncthreads();
+  // the straight-line epilogue (conv_device.h: epilogue_perm, round 4); tanh and outputs beyond 32-bit buffer offsets keep the
+  // general code below
+  const size_t ybytes = (size_t)p.N * p.Hout * p.Wout * p.Co * SZ;
+  if (p.act != MT_ACT_TANH && ybytes < 0x7f000000ull) {
+    unsigned yo[FP];
+    float vm[FP];
+#pragma unroll
+    for (int b = 0; b < FP; b++) {
+      yo[b] = yp[b] != nullptr ? (unsigned)(yp[b] - p.y) : EPI_OOB;
+      vm[b] = yp[b] != nullptr ? 1.f : 0.f;
+    }
+    const unsigned cob = (unsigned)(wt * WT + wcI * WC + fg * 8);
+    float* const red_lane = red + (wpI * WT + wcI * WC + fg * 8) * 2;
+    if (do_stats)
+      epilogue_perm<BF16, FC, FP, false, true, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm,
+                                                         cob, p.Co, red_lane, fr);
+    else
+      epilogue_perm<BF16, FC, FP, false, false, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm,
+                                                          cob, p.Co, red_lane, fr);
+  } else
   // Weight rows were staged in permuted order (see rl_perm above): fragment pair (2s, 2s+1) of lane-group fg
   // holds the 8 CONSECUTIVE channels s*32 + fg*8 .. +7 of one pixel, so a lane stores 16 bytes (bf16) per
   // pixel fragment and the four lane-groups of a store instruction cover 64 contiguous bytes per pixel --

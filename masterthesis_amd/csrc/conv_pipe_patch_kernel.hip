@@ -34,6 +34,18 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifdef MT_PP_STAMPS
+// diagnostic build only (tools/diag_build.sh NAME -DMT_PP_STAMPS conv_pipe_patch_kernel.hip): s_memtime stamps of wave 0 of every
+// block -> tools/stamp_k1.py
+__device__ unsigned long long mt_pp_stamp_buf[16 * 4096];
+#define PP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mt_pp_stamp_buf[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mt_debug_stamps(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mt_pp_stamp_buf), bytes < sizeof(mt_pp_stamp_buf) ? bytes : sizeof(mt_pp_stamp_buf));
+}
+#else
+#define PP_STAMP(i) do {} while (0)
+#endif
+
 #ifndef PP_PATCH_AUX
 #define PP_PATCH_AUX 0          // cache policy of the patch copies / weight copies (experiments: tools/diag_build.sh)
 #endif
@@ -92,6 +104,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   // [0..31] patch row offset per tap (the generic loop; the nine-tap loop keeps its addresses in registers)
   int* const sQ = reinterpret_cast<int*>(smem + NS * STAGE + 2 * PCAP * 4);
 
+  PP_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   }
   // ---- prologue: patch of slice 0, weight stages 0 .. NS-2 ----
   __builtin_amdgcn_sched_barrier(0);
+  PP_STAMP(1);
   for (int j = 0; j < nmine; j++) patch_piece(0, j, 0);
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) issue_weights(s);
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  PP_STAMP(2);
   int slot = 0;                 // ring slot of stage ks
   int c_prev = NWL;             // copies issued in the previous memory phase
   if constexpr (TAPS9) {
@@ -465,7 +480,21 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  PP_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing copies must have landed before LDS is reused / the wave exits
+  PP_STAMP(4);
+#ifdef MT_PP_EXP_NOEPI
+  {   // EXPERIMENT: no epilogue at all (the accumulators stay live through an impossible store)
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < FC; a++)
+#pragma unroll
+      for (int b = 0; b < FP; b++) t += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (t == 1.2345e-30f) p.y[threadIdx.x] = 1;
+    PP_STAMP(5);
+    return;
+  }
+#endif
 
   // ---- epilogue (igemm_pipe_kernel's): bias + activation, packed NHWC store, optional statistics ----
   char* yp[FP];
@@ -486,6 +515,30 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   const bool do_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(&smem[0]);      // [NWP][WT][2]
   if (do_stats) __syncthreads();
+  // ---- the straight-line epilogue (conv_device.h: epilogue_perm; round 4) for everything but tanh, the norm-backward statistics
+  // of the gradient (StatsLink, off by default) and outputs beyond the 32-bit buffer offsets, which keep the general code below
+  const size_t ybytes = (size_t)p.N * p.Hout * p.Wout * p.Co * SZ;
+  if (p.act != MT_ACT_TANH && p.bstat_x == nullptr && !(do_stats && p.addend != nullptr) && ybytes < 0x7f000000ull) {
+    unsigned yo[FP];
+    float vm[FP];
+#pragma unroll
+    for (int b = 0; b < FP; b++) {
+      yo[b] = yp[b] != nullptr ? (unsigned)(yp[b] - p.y) : EPI_OOB;
+      vm[b] = yp[b] != nullptr ? 1.f : 0.f;
+    }
+    const unsigned cob = (unsigned)(wt * WT + wcI * WC + fg * 8);
+    float* const red_lane = red + (wpI * WT + wcI * WC + fg * 8) * 2;
+    // (the forward with statistics and the data gradient with / without the skip gradient: three straight-line copies)
+    if (do_stats)
+      epilogue_perm<BF16, FC, FP, false, true, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm, cob,
+                                                      p.Co, red_lane, fr);
+    else if (p.addend != nullptr)
+      epilogue_perm<BF16, FC, FP, true, false, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, p.addend, p.act, p.slope, yo, vm,
+                                                      cob, p.Co, red_lane, fr);
+    else
+      epilogue_perm<BF16, FC, FP, false, false, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm,
+                                                       cob, p.Co, red_lane, fr);
+  } else
 #pragma unroll
   for (int sp = 0; sp < FC / 2; sp++) {
     const int col = wcI * WC + sp * 32 + fg * 8;
@@ -581,6 +634,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
       }
     }
   }
+  PP_STAMP(5);
 }
 
 static long g_pp_launches = 0;

@@ -21,11 +21,14 @@ buf = np.zeros(16 * 4096, dtype=np.uint64)
 lib.mt_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 rc = lib.mt_debug_stamps(buf.ctypes.data, buf.nbytes)
 nb = N * 64 * 64 // 256
-s = buf.reshape(4096, 16)[:nb, :4].astype(np.int64)
-acc = buf.reshape(4096, 16)[:nb, 8:16].astype(np.int64)
+NS = int(os.environ.get("MT_STAMP_COUNT", "4"))          # 4: conv_pipe_kernel.hip (MT_STAMPS); 6: conv_pipe_patch_kernel.hip (MT_PP_STAMPS)
+s = buf.reshape(4096, 16)[:nb, :NS].astype(np.int64)
 d = np.diff(s, axis=1)
+names = {4: ["prologue", "mainloop", "epilogue"], 6: ["setup", "first copies + addresses", "mainloop", "drain", "epilogue"]}[NS]
 print("rc", rc, "blocks", nb)
-print("median cycles: prologue %d  mainloop %d  epilogue %d  total %d" % tuple(list(np.median(d, axis=0)) + [np.median(s[:, 3] - s[:, 0])]))
-print("p90    cycles: prologue %d  mainloop %d  epilogue %d" % tuple(np.percentile(d, 90, axis=0)))
-print("span first start -> last end: %d cycles" % (s[:, 3].max() - s[:, 0].min()))
-print("start spread: %d  end spread: %d" % (s[:, 0].max() - s[:, 0].min(), s[:, 3].max() - s[:, 3].min()))
+print("median cycles: " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, np.median(d, axis=0))) + f"  total {int(np.median(s[:, -1] - s[:, 0]))}")
+print("p90    cycles: " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, np.percentile(d, 90, axis=0))))
+print("span first start -> last end: %d cycles" % (s[:, -1].max() - s[:, 0].min()))
+print("start spread: %d  end spread: %d" % (s[:, 0].max() - s[:, 0].min(), s[:, -1].max() - s[:, -1].min()))
+for i in range(NS):
+    print(f"stamp {i}: min {int(s[:, i].min() - s[:, 0].min())}  median {int(np.median(s[:, i]) - s[:, 0].min())}  max {int(s[:, i].max() - s[:, 0].min())}")
