@@ -51,6 +51,7 @@ __device__ __forceinline__ void epilogue_perm(const f32x4 (&acc)[FC][FP], char* 
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias != nullptr ? (unsigned)nbias * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)addend, 0, HAS_ADD ? ybytes : 0u, 0x00020000);
   const float neg = act == MT_ACT_RELU ? 0.f : (act == MT_ACT_LRELU ? slope : 1.f);
+  const bool relu = act == MT_ACT_RELU;
   constexpr int NA = BF16 ? 1 : 2;                   // 16-byte pieces of 8 channels
   constexpr bool AHEAD = BF16;                       // the next group's addend in flight (fp32: 64 more registers -- not there)
   u32x4 adc[FP][NA], adn[FP][NA];
@@ -87,7 +88,7 @@ __device__ __forceinline__ void epilogue_perm(const f32x4 (&acc)[FC][FP], char* 
       for (int e = 0; e < 8; e++) {
         const float z = acc[2 * sp + (e >> 2)][b][e & 3] + bvc[e];
         if constexpr (TANH) v[e] = tanhf(z);
-        else v[e] = fmaxf(z, 0.f) + neg * fminf(z, 0.f);
+        else v[e] = fmaxf(z, 0.f) + (relu ? 0.f : neg * fminf(z, 0.f));        // (select: relu(-inf) = 0, not 0 * -inf)
       }
       if constexpr (HAS_ADD) {
         float ad[8];

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void igemm_wsreg_kernel(const IgemmParams p, c
           for (int e = 0; e < 4; e++) {
             // branch-free none / ReLU / LeakyReLU: max(v, 0) + ns * min(v, 0) with ns = 1 / 0 / slope (tanh: host refuses)
             const float v0 = acc[q][cf][e] + bv[cf * 4 + e];
-            vv[cf * 4 + e] = fmaxf(v0, 0.f) + act_ns * fminf(v0, 0.f);
+            vv[cf * 4 + e] = fmaxf(v0, 0.f) + (act_ns == 0.f ? 0.f : act_ns * fminf(v0, 0.f));     // (select: relu(-inf) = 0)
           }
         if constexpr (STATS) {
           if (ok) {

@@ -13,8 +13,18 @@ ops.set_compute_dtype(torch.bfloat16)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 x = ops.canon(torch.randn(N, 256, 64, 64, device=dev))
 w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
-with torch.no_grad():
-    for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
+if len(sys.argv) > 2 and sys.argv[2] == "dgrad":      # the last launch of the stamped kernel is then the data gradient
+    x.requires_grad_(True)
+    gy = None
+    for _ in range(10):
+        y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
+        if gy is None:
+            gy = ops.canon(torch.randn_like(y.float())).detach()
+        y.backward(gy)
+        x.grad = None
+else:
+    with torch.no_grad():
+        for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
 buf = np.zeros(16 * 4096, dtype=np.uint64)
