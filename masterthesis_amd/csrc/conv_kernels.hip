@@ -28,8 +28,10 @@ __device__ unsigned long long mt_stamp_buf2[8 * 16384];
 extern "C" int mt_debug_stamps2(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mt_stamp_buf2), bytes < sizeof(mt_stamp_buf2) ? bytes : sizeof(mt_stamp_buf2));
 }
+#define MT_STAMP2_END() do { MT_STAMP2(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MT_STAMP2(5); } while (0)
 #else
 #define MT_STAMP2(i) do {} while (0)
+#define MT_STAMP2_END() do {} while (0)
 #endif
 
 // Tile geometries (WT output channels x PT pixels per block, NT threads):
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
       const unsigned cob = (unsigned)(wt * WT + wcI * WC + fg * 8);
       if (p.raw) {
         epilogue_perm_raw<FC, FP>(acc, ybase, (unsigned)ybytes, yo, cob, p.Co);
+        MT_STAMP2_END();
         return;
       }
       const bool stats_f = p.stats != nullptr;
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
           }
         }
       }
+      MT_STAMP2_END();
       return;
     }
   }

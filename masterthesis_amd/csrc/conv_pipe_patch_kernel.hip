@@ -270,10 +270,6 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   };
 
   f32x4 acc[FC][FP];
-#pragma unroll
-  for (int a = 0; a < FC; a++)
-#pragma unroll
-    for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // (tap offsets of the nine-tap loop: read before any copy is in flight -- a dynamically indexed short in the kernel
   //  arguments is a vector load, and its wait would drain the LDS-DMA queue)
@@ -291,8 +287,12 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   for (int j = 0; j < nmine; j++) patch_piece(0, j, 0);
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) issue_weights(s);
-  // (the fragment addresses are computed while those copies are in flight)
+  // (the accumulators are cleared and the fragment addresses computed while those copies are in flight)
   __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int a = 0; a < FC; a++)
+#pragma unroll
+    for (int b = 0; b < FP; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   // TAPS9: LDS byte offset (from the start of the shared array, patch slot 0; slot 1 is a constant further, which fits
   // the DS instruction's 16-bit immediate) of this lane's chunk of fragment b at tap t
   int qa[9][FP];

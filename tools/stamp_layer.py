@@ -1,5 +1,5 @@
 """In-kernel s_memtime stamps of the 2-stage gather-GEMM on one layer (diagnostic build:
-tools/diag_build.sh st2 -DMT_STAMPS2 conv_kernels.hip; run with MT_DIAG_LIB=_diag/libmt_st2.so).
+tools/diag_build.sh st2 -DMT_STAMPS2 conv_kernels.hip; run with MT_DIAG_LIB=_exp/libmt_st2.so).
 usage: stamp_layer.py N Cin H Cout k stride [T for transposed]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
