@@ -349,7 +349,9 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
         // virtual cells of the NEXT slice's patch: its copies went out in steps 0 .. 3 of this slice and have landed, for
         // every wave, once group 0 enters step 6 (nmine <= 4 with FOLD: host).  First thing in the step, before the
         // fragments of this step occupy their registers.
+#ifndef MT_PP_EXP_NOVIRT
         if (grp == 0 && sl_c + 1 < nsl) build_virtual(PAR ^ 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       u32x4 wf[FC], xf[FP];

@@ -23,8 +23,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "dgrad":      # the last launch of the s
         y.backward(gy)
         x.grad = None
 else:
+    pm = "zero" if len(sys.argv) > 2 and sys.argv[2] == "fwdzero" else "reflect"
     with torch.no_grad():
-        for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode="reflect")
+        for _ in range(20): y = ops.conv2d(x, w, None, stride=1, pad=1, pad_mode=pm)
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
 buf = np.zeros(16 * 4096, dtype=np.uint64)
