@@ -121,9 +121,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   const int nsl = p.cpc >> 2;                  // 64-byte channel slices
   const int nk = ntaps * nsl;
 
-  if (tid < 32) {
-    const int dh = tid < ntaps ? (int)p.dh[ph.tap0 + tid] : 0, dw = tid < ntaps ? (int)p.dw[ph.tap0 + tid] : 0;
-    sQ[tid] = tid < ntaps ? (dh - dh0) * PW + (dw - dw0) : 0;
+  // (the nine-tap loop keeps its addresses in registers: no table, and no lane-indexed load of the tap offsets -- a vector load whose
+  //  wait held wave 0, and with it every barrier of the prologue, for a memory latency at the very start of the tile)
+  if constexpr (!TAPS9) {
+    if (tid < 32) {
+      const int dh = tid < ntaps ? (int)p.dh[tid] : 0, dw = tid < ntaps ? (int)p.dw[tid] : 0;        // (host: tap0 == 0)
+      sQ[tid] = tid < ntaps ? (dh - dh0) * PW + (dw - dw0) : 0;
+    }
   }
 
   // ---- the tile: 256 consecutive pixels of one image = TH full rows (host: 256 % Wo == 0, HoWo % 256 == 0) ----
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   if constexpr (TAPS9) {
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-      tdh[t] = __builtin_amdgcn_readfirstlane((int)p.dh[ph.tap0 + t]);
-      tdw[t] = __builtin_amdgcn_readfirstlane((int)p.dw[ph.tap0 + t]);
+      tdh[t] = (int)p.dh[t];            // (host: tap0 == 0 -- constant offsets into the kernel arguments: scalar loads)
+      tdw[t] = (int)p.dw[t];
     }
   }
   // ---- prologue: patch of slice 0, weight stages 0 .. NS-2 ----
@@ -660,7 +664,7 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
   if (p.nphase != 1 || p.raw || p.is != 1 || p.cpc % 4 != 0 || p.CoRows % 256 != 0) return -1;
   const int Wo = q.Wo, Ho = q.Ho;
   if (Wo < 16 || Wo > 256 || (Wo & (Wo - 1)) != 0 || (Ho * Wo) % 256 != 0 || q.M != p.N * Ho * Wo) return -1;
-  if (q.ntaps > MT_PP_MAXTAPS || q.ntaps < 2 || q.y_off != 0) return -1;
+  if (q.ntaps > MT_PP_MAXTAPS || q.ntaps < 2 || q.y_off != 0 || q.tap0 != 0) return -1;
   int shift = 0;
   while ((1 << shift) < Wo) shift++;
   const int TH = 256 / Wo;
