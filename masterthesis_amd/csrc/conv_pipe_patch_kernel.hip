@@ -172,16 +172,27 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   // FOLD: which fragments hold the rows / columns that receive reflected contributions (wave-uniform per fragment), and
   // which lane holds the column
   // virtual cells of a patch slot (FOLD), as patch rows behind the real ones:
-  //   VL[i] = prows + i, VR[i] = prows + PH + i              (i = patch row)
-  //   VT[j] = prows + 2 PH + j, then VT_L, VT_R;  VB[j] = prows + 2 PH + PW + 2 + j, then VB_L, VB_R   (j = patch column)
-  const int vL0 = prows, vR0 = prows + PH, vT0 = prows + 2 * PH, vB0 = prows + 2 * PH + PW + 2;
+  //   VL[i], VR[i] (i = patch row): ONE lane of a border fragment reads such a cell in place of the patch row i PW + 3 (left:
+  //   its pixel is column 1, tap dw = +1) resp. i PW + Wo - 2 (right) while the other 15 lanes read consecutive patch rows.  The
+  //   cell therefore sits at a row with the SAME residue mod 8 as the row it stands in for (same banks, same swizzle key): with
+  //   VL[i] = prows + i the substituted lane collided with its neighbours in every border fragment read of every step
+  //   (SQ_LDS_BANK_CONFLICT 0 in the forward, 337 k in the data gradient; +10 k cycles per tile).  PW = Wo + 2 = 2 (mod 8): four
+  //   consecutive i have four distinct residues -- odd ones on the left, even ones on the right -- so 8 rows hold the cells of 4
+  //   patch rows for both sides.
+  //   VT[j] = vT0 + j, then VT_L, VT_R;  VB[j] = vB0 + j, then VB_L, VB_R   (j = patch column; whole fragments read these)
+  const int PH4 = (PH + 3) >> 2;
+  const int vLb = (prows + 7) & ~7, vT0 = vLb + 8 * PH4, vB0 = vT0 + PW + 2;
+  // (i PW + 3 and i PW + Wo - 2 mod 8 with PW = 2, Wo = 0 mod 8 -- host: shifts and masks only, these sit in the address set-up)
+  auto vL = [&](int i) { return vLb + ((i >> 2) << 3) + ((2 * i + 3) & 7); };
+  auto vR = [&](int i) { return vLb + ((i >> 2) << 3) + ((2 * i + 6) & 7); };
   const bool tileT = FOLD && ho0 <= 1 && 1 < ho0 + (PT >> wo_shift);                       // the tile holds row 1 / row H-2
   const bool tileB = FOLD && ho0 <= p.Hi - 2 && p.Hi - 2 < ho0 + (PT >> wo_shift);
   bool f_rT[FP], f_rB[FP], f_hasL[FP], f_hasR[FP], f_cL[FP], f_cR[FP];
   int f_ly[FP], f_lx[FP];
 #pragma unroll
   for (int b = 0; b < FP; b++) {
-    const int tpb = wpI * WP + b * 16;                   // (uniform: 16 divides the map width)
+    const int tpb = __builtin_amdgcn_readfirstlane(wpI) * WP + b * 16;     // (wave-uniform, and known to the compiler as such: the
+                                                                           //  fragment's flags and cell rows stay on the scalar unit)
     const int u = ho0 + (tpb >> wo_shift), c0 = tpb & (ph_Wo - 1);
     f_ly[b] = tpb >> wo_shift;
     f_lx[b] = c0 + fr;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
       if (c < 2 * PH) {
         const bool right = c >= PH;
         const int i = right ? c - PH : c;
-        dst = (right ? vR0 : vL0) + i;
+        dst = right ? vR(i) : vL(i);
         a0 = i * PW + (right ? jR0 : jL0);
         a1 = i * PW + (right ? jR2 : jL2);
       } else {
@@ -315,7 +326,8 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
           if (rh) q = vrow + f_lx[b] + dw + 1;                                      // VT / VB cell of column v + dw
           if (ch) {
             const bool cl = dw > 0 ? f_cL[b] : f_cR[b];                             // this lane's pixel is the column
-            const int alt = rh ? vrow + PW + (dw > 0 ? 0 : 1) : (dw > 0 ? vL0 : vR0) + f_ly[b] + dh + 1;
+            const int ci = f_ly[b] + dh + 1;                                            // vL(ci) / vR(ci), the side chosen first
+            const int alt = rh ? vrow + PW + (dw > 0 ? 0 : 1) : vLb + ((ci >> 2) << 3) + ((2 * ci + (dw > 0 ? 3 : 6)) & 7);
             q = cl ? alt : q;
           }
         }
@@ -324,12 +336,15 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     }
   }
 
+  PP_STAMP(6);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NWL) : "memory");
   __syncthreads();              // sQ visible; every wave's patch rows and stage 0 have landed
+  PP_STAMP(7);
   if constexpr (FOLD) {
     if (tid < 256) build_virtual(0);
     __syncthreads();
   }
+  PP_STAMP(8);
 
   // ---- ping-pong main loop (see igemm_pipe_kernel): waves 0-3 and 4-7 alternate between a MEMORY phase (copies of
   // stage ks+NS-1 and of the next slice's patch, fragment reads of stage ks) and a COMPUTE phase (32 MFMAs) ----
@@ -685,7 +700,7 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
         p.pad_mode != MT_PAD_ZERO || p.os != 1 || (p.stats != nullptr && p.bstat_x == nullptr))
       return -1;
     // the virtual cells live behind the patch rows; the next slice's copies must all be out by step 3 (they are built in step 6)
-    if (PH * PW + 2 * PH + 2 * (PW + 2) > MT_PP_PCAP || nmine > 4) return -1;
+    if (((PH * PW + 7) & ~7) + 8 * ((PH + 3) / 4) + 2 * (PW + 2) > MT_PP_PCAP || nmine > 4 || (PW & 7) != 2) return -1;
   }
   if (dry) return 102;
   if (p.fold)

@@ -682,6 +682,11 @@ extern "C" int mt_norm_bwd_apply(int dtype, const void* dy, const void* x, const
 #ifndef MT_OP_STORE_AUX
 #define MT_OP_STORE_AUX 2                   // cache policy of the dx stores (2 = nt, as mt_norm_bwd_apply's streaming stores)
 #endif
+#ifdef MT_OP_MINW                           // (experiments: at least this many waves per SIMD, i.e. a register cap)
+#define MT_OP_BOUNDS __launch_bounds__(MT_OP_THREADS, MT_OP_MINW)
+#else
+#define MT_OP_BOUNDS __launch_bounds__(MT_OP_THREADS)
+#endif
 constexpr int MT_OP_NT = MT_OP_THREADS;
 constexpr int MT_OP_SLICE = MT_OP_THREADS * MT_OP_PAIRS;   // 16-byte chunks of x (and of dy) per workgroup
 // Polls (~1 us each) before a waiting workgroup gives up and poisons its output with NaN (never a hang).  A normal wait is the
@@ -691,7 +696,7 @@ constexpr int MT_OP_SLICE = MT_OP_THREADS * MT_OP_PAIRS;   // 16-byte chunks of 
 // limit); masterthesis_amd/distributed.py switches the kernel off when ranks share a device.
 constexpr int MT_OP_SPIN = 1 << 19;
 template <int CCH, int NT, int P>
-__global__ __launch_bounds__(NT) void norm_bwd_onepass_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+__global__ MT_OP_BOUNDS void norm_bwd_onepass_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gb, float* __restrict__ dgb,

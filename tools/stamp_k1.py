@@ -41,5 +41,9 @@ print("median cycles: " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, np.me
 print("p90    cycles: " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, np.percentile(d, 90, axis=0))))
 print("span first start -> last end: %d cycles" % (s[:, -1].max() - s[:, 0].min()))
 print("start spread: %d  end spread: %d" % (s[:, 0].max() - s[:, 0].min(), s[:, -1].max() - s[:, -1].min()))
+full = buf.reshape(4096, 16)[:nb].astype(np.int64)
+if NS == 6 and (full[:, 6] > 0).all():
+    print("inside the prologue (cycles after stamp 1): addresses done %d, first data landed + barrier %d, virtual cells %d" % tuple(
+        int(np.median(full[:, k] - full[:, 1])) for k in (6, 7, 8)))
 for i in range(NS):
     print(f"stamp {i}: min {int(s[:, i].min() - s[:, 0].min())}  median {int(np.median(s[:, i]) - s[:, 0].min())}  max {int(s[:, i].max() - s[:, 0].min())}")
