@@ -34,6 +34,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef MT_PP_EPI_AUX
+#define MT_PP_EPI_AUX 2      // cache policy of the output stores (2 = nt: streaming; A/B builds: 0)
+#endif
 #ifdef MT_PP_STAMPS
 // diagnostic build only (tools/diag_build.sh NAME -DMT_PP_STAMPS conv_pipe_patch_kernel.hip): s_memtime stamps of wave 0 of every
 // block -> tools/stamp_k1.py
@@ -551,13 +554,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
     float* const red_lane = red + (wpI * WT + wcI * WC + fg * 8) * 2;
     // (the forward with statistics and the data gradient with / without the skip gradient: three straight-line copies)
     if (do_stats)
-      epilogue_perm<BF16, FC, FP, false, true, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm, cob,
+      epilogue_perm<BF16, FC, FP, false, true, false, MT_PP_EPI_AUX>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm, cob,
                                                       p.Co, red_lane, fr);
     else if (p.addend != nullptr)
-      epilogue_perm<BF16, FC, FP, true, false, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, p.addend, p.act, p.slope, yo, vm,
+      epilogue_perm<BF16, FC, FP, true, false, false, MT_PP_EPI_AUX>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, p.addend, p.act, p.slope, yo, vm,
                                                       cob, p.Co, red_lane, fr);
     else
-      epilogue_perm<BF16, FC, FP, false, false, false, 2>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm,
+      epilogue_perm<BF16, FC, FP, false, false, false, MT_PP_EPI_AUX>(acc, p.y, (unsigned)ybytes, p.bias, p.nbias, nullptr, p.act, p.slope, yo, vm,
                                                        cob, p.Co, red_lane, fr);
   } else
 #pragma unroll
