@@ -95,6 +95,15 @@ CONV_CASES = [
     ("k3s1_co40_big", 8, 32, 128, 128, 40, 3, 1, 1, "zero", False, None),        # ... with a partial channel tile
     # many channels + bias: the two-stage bias-gradient reduction over > 512 pixel blocks
     ("k3s1_bias_big", 2, 16, 160, 160, 48, 3, 1, 1, "reflect", True, "lrelu"),
+    # the straight-line epilogue (conv_device.h: epilogue_perm, round 4): absent pixels / channels are out-of-range buffer offsets,
+    # the bias is range-checked -- channel counts off the tile width on the 256x256 kernels, a second channel tile that is mostly
+    # padding, a ragged pixel count on the ping-pong tiles, and tanh (which keeps the general epilogue) on a wide layer
+    # (no activation on the two 10^7-output cases: an fp32 mask flips on a few within-rounding-of-zero elements, see above)
+    ("k3s1_tile256_co250", 16, 256, 64, 64, 250, 3, 1, 1, "reflect", True, None),
+    ("k3s1_tile256_co264", 16, 64, 64, 64, 264, 3, 1, 1, "zero", True, "relu"),
+    ("k3s1_pipe512_ragged", 7, 64, 100, 90, 128, 3, 1, 1, "reflect", True, None),
+    ("k3s1_co100_big", 6, 40, 120, 136, 100, 3, 1, 1, "zero", True, None),
+    ("k3s1_tanh_wide", 4, 64, 64, 64, 256, 3, 1, 1, "reflect", True, "tanh"),
 ]
 
 
