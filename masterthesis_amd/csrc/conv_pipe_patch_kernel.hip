@@ -317,8 +317,10 @@ __global__ __launch_bounds__(512) void igemm_pipe_patch_kernel(const IgemmParams
   if constexpr (TAPS9) {
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-      const int dh = tdh[t], dw = tdw[t];
-      const int qo = (dh - dh0) * PW + (dw - dw0);
+      // (FOLD: the host admits the 3x3 window in the order of the data-gradient pack only -- dh = 1 - t / 3, dw = 1 - t % 3 -- so the
+      //  border selects below fold at compile time: with run-time offsets they were ~850 vector instructions of the address set-up)
+      const int dh = FOLD ? 1 - t / 3 : tdh[t], dw = FOLD ? 1 - t % 3 : tdw[t];
+      const int qo = (dh - (FOLD ? -1 : dh0)) * PW + (dw - (FOLD ? -1 : dw0));
 #pragma unroll
       for (int b = 0; b < FP; b++) {
         int q = q0[b] + qo;
@@ -699,6 +701,8 @@ int launch_igemm_pipe_patch_t(IgemmParams& p, int total, hipStream_t s, bool dry
   if (p.x_bytes >= 0x7f000000u || q.w_bytes >= 0x3f000000u) return -1;
   if (p.fold) {
     // the in-operand fold is written for a 3x3 window at offsets -1 .. 1 on a map of the output's size (pad 1)
+    for (int t = 0; t < q.ntaps && t < 9; t++)
+      if (p.dh[t] != 1 - t / 3 || p.dw[t] != 1 - t % 3) return -1;      // (the kernel's address set-up has this order compiled in)
     if (q.ntaps != 9 || dhmin != -1 || dhmax != 1 || dwmin != -1 || dwmax != 1 || p.Hi < 4 || p.Wi < 4 || p.Hi != Ho || p.Wi != Wo ||
         p.pad_mode != MT_PAD_ZERO || p.os != 1 || (p.stats != nullptr && p.bstat_x == nullptr))
       return -1;
