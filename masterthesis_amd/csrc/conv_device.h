@@ -16,6 +16,20 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x
   }
 }
 
+// Filter-tap offsets of the parameter block through DWORD loads: with a wave-uniform index these are scalar loads from the kernel
+// arguments; a dynamically indexed `short` is fetched with a VECTOR load (global_load_sshort) whose wait stands in front of a tile's
+// first copy (and, in igemm_pipe_kernel's table loop, once per pair of taps: a chain of memory latencies per tile -- round 4).
+template <class P>
+__device__ __forceinline__ int tap_dh(const P& p, int t) {
+  const int w = reinterpret_cast<const int*>(p.dh)[t >> 1];
+  return (int)(short)((t & 1) ? (w >> 16) : w);
+}
+template <class P>
+__device__ __forceinline__ int tap_dw(const P& p, int t) {
+  const int w = reinterpret_cast<const int*>(p.dw)[t >> 1];
+  return (int)(short)((t & 1) ? (w >> 16) : w);
+}
+
 // bijective XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
 // contiguous range of tiles so neighbouring pixel tiles (shared halo rows) hit the same L2.
 __device__ __forceinline__ int xcd_remap(int b, int nblk) {

@@ -74,9 +74,11 @@ __global__ __launch_bounds__(512) void igemm_kernel(const IgemmParams p) {
   const int ph_nchunks = ph_ntaps * p.cpc;
   const char* const ph_w = p.w + ph.w_off;
   wg -= ph.blk0;
-  if (tid < 64) {
-    const int t = ph.tap0 + tid;
-    sTap[tid] = tid < ph_ntaps ? (((int)p.dh[t] << 16) | ((int)p.dw[t] & 0xffff)) : 0;
+  // (one tap per iteration and wave, index wave-uniform: scalar loads from the kernel arguments.  Lane-indexed they were two vector
+  //  loads whose wait stood between the launch and the first copy of every tile)
+  for (int t = __builtin_amdgcn_readfirstlane(tid >> 6); t < ph_ntaps && t < 64; t += NT / 64) {     // (entries >= ntaps are never read)
+    const int v = (tap_dh(p, ph.tap0 + t) << 16) | (tap_dw(p, ph.tap0 + t) & 0xffff);
+    if ((tid & 63) == 0) sTap[t] = v;
   }
   const int wt = wg % nWT, pt = wg / nWT;
 

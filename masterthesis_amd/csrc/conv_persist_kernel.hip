@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, BPC) void igemm_persist_kernel(const IgemmPara
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   // launch-wide tables
-  if (tid < MT_MAX_TAPS) sTap[tid] = ((int)p.dh[tid] << 16) | ((int)p.dw[tid] & 0xffff);
+  for (int t = __builtin_amdgcn_readfirstlane(tid >> 6); t < MT_MAX_TAPS; t += 4) {       // (wave-uniform index: scalar loads)
+    const int v = (tap_dh(p, t) << 16) | (tap_dw(p, t) & 0xffff);
+    if ((tid & 63) == 0) sTap[t] = v;
+  }
   for (int i = tid; i < p.Co + 8 && i < MT_PERSIST_MAX_CO; i += 256)
     sBias[i] = (p.bias != nullptr && i < p.nbias) ? p.bias[i] : 0.f;
 

@@ -104,10 +104,13 @@ __global__ __launch_bounds__(512) void igemm_pipe_kernel(const IgemmParams p) {
     const int ho = rem / ph_Wo;
     const int wo = rem - ho * ph_Wo;
     const unsigned ibase = (unsigned)n * (unsigned)(p.Hi * p.Wi) * (unsigned)p.Cib;
-    for (int t = tid / PT; t <= ph_ntaps; t += NT / PT) {
+    // (t is the same for a whole wave: said so, the tap offsets are SCALAR loads from the kernel arguments.  As lane-indexed shorts
+    //  they were vector loads with a full wait inside this loop -- a chain of ntaps / 2 memory latencies in front of the first copy of
+    //  every tile: round 4, found next to the same pattern in the patch-resident kernel)
+    for (int t = __builtin_amdgcn_readfirstlane(tid / PT); t <= ph_ntaps; t += NT / PT) {
       unsigned off = OOB;
       if (t < ph_ntaps) {
-        int hi = ho * p.is + p.dh[ph.tap0 + t], wi = wo * p.is + p.dw[ph.tap0 + t];
+        int hi = ho * p.is + tap_dh(p, ph.tap0 + t), wi = wo * p.is + tap_dw(p, ph.tap0 + t);
         bool ok = rv;
         if (p.pad_mode == MT_PAD_REFLECT) {
           hi = hi < 0 ? -hi : hi;
