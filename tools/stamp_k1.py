@@ -11,8 +11,9 @@ from masterthesis_amd import hip_ops as ops
 dev = torch.device('cuda:0')
 ops.set_compute_dtype(torch.bfloat16)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-x = ops.canon(torch.randn(N, 256, 64, 64, device=dev))
-w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
+Ci, Co, H, W = [int(v) for v in os.environ.get("MT_STAMP_SHAPE", "256,256,64,64").split(",")]     # (3x3 stride 1, reflection padding)
+x = ops.canon(torch.randn(N, Ci, H, W, device=dev))
+w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.05
 if len(sys.argv) > 2 and sys.argv[2] == "dgrad":      # the last launch of the stamped kernel is then the data gradient
     x.requires_grad_(True)
     gy = None
@@ -31,7 +32,7 @@ lib = C.CDLL(_lib.LIB_PATH)
 buf = np.zeros(16 * 4096, dtype=np.uint64)
 lib.mt_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 rc = lib.mt_debug_stamps(buf.ctypes.data, buf.nbytes)
-nb = N * 64 * 64 // 256
+nb = int(os.environ.get("MT_STAMP_BLOCKS", N * H * W // 256 * max(Co // 256, 1)))
 NS = int(os.environ.get("MT_STAMP_COUNT", "4"))          # 4: conv_pipe_kernel.hip (MT_STAMPS); 6: conv_pipe_patch_kernel.hip (MT_PP_STAMPS)
 s = buf.reshape(4096, 16)[:nb, :NS].astype(np.int64)
 d = np.diff(s, axis=1)
