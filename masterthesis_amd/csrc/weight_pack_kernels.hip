@@ -60,11 +60,15 @@ __global__ void pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
 template <bool BF16>
 __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, char* smraw, unsigned char* s_t) {
   typedef typename std::conditional<BF16, unsigned short, float>::type T;
-  constexpr int PL = 32 * 32 + 8;                    // elements per plane
+  constexpr int PL = 32 * 32 + 8;                    // elements per plane of the straight copy
+  // the transposed copy: 40-element rows (80 bytes: 16-byte reads stay aligned).  With 32-element rows a wave's transposed writes
+  // (lanes = 4 taps x 16 d1) met in 4 of the 64 banks -- 16-way conflicts on half of the tile's LDS writes: SQ_LDS_BANK_CONFLICT
+  // was 77 % of this kernel's LDS-active cycles (round 4, tools/pmc_lds_conflicts.py); with 20-dword rows they spread over 16
+  constexpr int RB = 40, PLB = 32 * RB + 8;
   constexpr int EV = BF16 ? 8 : 4;                   // elements per 16 bytes
   T* const sA = reinterpret_cast<T*>(smraw);         // [k][d0l][d1l]
   const int K2 = g.K2;
-  T* const sB = sA + K2 * PL;                        // [k][d1l][d0l]
+  T* const sB = sA + K2 * PL;                        // [k][d1l][d0l], row pitch RB
   const int td0 = tile / g.tiles_d1, td1 = tile - td0 * g.tiles_d1;
   const int d00 = td0 * 32, d10 = td1 * 32;
   const int run = 32 * K2;                            // floats of one d0 row of the tile (contiguous in the source)
@@ -76,9 +80,33 @@ __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, ch
     T e;
     if constexpr (BF16) e = f32_to_bf16_bits(v); else e = v;
     sA[k * PL + d0l * 32 + d1l] = e;
-    sB[k * PL + d1l * 32 + d0l] = e;
+    sB[k * PLB + d1l * RB + d0l] = e;
   };
-  if (vec) {
+  if (vec && K2 == 16 && BF16) {
+    // 4x4 filters (the discriminators: 9 of every 10 packed bytes), bf16: a thread keeps ONE float4 column (4 taps of one d1) and walks
+    // the 32 d0 rows in adjacent PAIRS, so the transposed copy is written with 4-byte stores (two d0 of one (tap, d1)): half the LDS
+    // write instructions of the element-wise scatter below.  All 16 loads of the thread are in flight first.
+    const int j4 = (int)threadIdx.x & 127, hh = (int)threadIdx.x >> 7;        // float4 column, half of the row pairs
+    const int d1l = j4 >> 2, k0 = (j4 & 3) * 4;
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int d0l = 4 * (i >> 1) + 2 * hh + (i & 1);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      v[i] = (d00 + d0l < g.D0) ? reinterpret_cast<const f32x4*>(g.w + ((long)(d00 + d0l) * g.D1 + d10) * K2)[j4] : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const int d0l = 4 * (i >> 1) + 2 * hh;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const unsigned short lo = f32_to_bf16_bits(v[i][e]), hi = f32_to_bf16_bits(v[i + 1][e]);
+        sA[(k0 + e) * PL + d0l * 32 + d1l] = lo;
+        sA[(k0 + e) * PL + (d0l + 1) * 32 + d1l] = hi;
+        *reinterpret_cast<unsigned*>(sB + (k0 + e) * PLB + d1l * RB + d0l) = (unsigned)lo | ((unsigned)hi << 16);
+      }
+    }
+  } else if (vec) {
     // the whole tile (32 rows x 8 K2 float4, <= 4096) in flight at once: up to 16 independent 16-byte loads per thread, THEN the
     // LDS scatter (round 4: one row per iteration with half the block idle was a chain of 32 memory latencies per tile --
     // 230 us for a discriminator's 44.7 M weights, 1.5 TB/s)
@@ -130,7 +158,7 @@ __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, ch
       const int rl = (int)(((float)q + 0.5f) * inv_nt), t = q - rl * nt;
       const int r = r0 + rl, c = c0 + ch * EV;
       if (r < Rp && c < Cp) {            // (Cp is a multiple of 8: a chunk is inside or outside as a whole)
-        const u32x4 v = *reinterpret_cast<const u32x4*>(sS + (int)s_t[t] * PL + rl * 32 + ch * EV);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sS + (int)s_t[t] * (rows_d0 ? PL : PLB) + rl * (rows_d0 ? 32 : RB) + ch * EV);
         const long di = ((long)r * nt + t) * Cp + c;
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(o.out) + di) = v;
       }
@@ -139,7 +167,7 @@ __device__ __forceinline__ void pack_group_tile(const PackGroup& g, int tile, ch
   }
 }
 __global__ __launch_bounds__(256) void pack_group_kernel(const PackGroup* __restrict__ groups, int ng) {
-  __shared__ __attribute__((aligned(16))) char sm[2 * 16 * (32 * 32 + 8) * 2];       // two copies, 16 taps, bf16 elements (fp32 images take the element-wise kernel)
+  __shared__ __attribute__((aligned(16))) char sm[16 * ((32 * 32 + 8) + (32 * 40 + 8)) * 2];   // two copies (the transposed one with 40-element rows), 16 taps, bf16 elements (fp32 images take the element-wise kernel)
   __shared__ unsigned char s_t[MT_MAX_TAPS];
   const int total_tiles = groups[ng - 1].tile0 + groups[ng - 1].ntiles;
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
