@@ -617,11 +617,16 @@ extern "C" int mt_conv_bwd_data_ex(const mt_conv_desc* d, const void* dy, const 
 
 // pixel-split of the weight-gradient reduction: enough (tile, split) blocks to fill 256 CUs x 2
 // *pipe: the 256x256 ping-pong kernel takes the problem (then the split fills one 8-wave block per CU)
-static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, bool* pipe = nullptr) {
+static void wgrad_params(const mt_conv_desc* d, const void* x, const void* dy, WgradParams* pp);
+static int wgrad_pixels(const mt_conv_desc* d);
+// *pipe: 1 the 256x256 ping-pong kernel takes the problem (then the split fills one 8-wave block per CU), 2 the
+// accumulator-stationary kernel of the 3x3 layers does (*mchunk = output ROWS per split then), 0 the 128x128 tile kernel
+static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, int* pipe = nullptr) {
   const int V = vec(d->dtype);
   const int Cip = mt_padc(d->Ci), Cop = mt_padc(d->Co), K2 = d->kh * d->kw;
   const int rows = d->transposed ? Cip : Cop, cols = (d->transposed ? Cop : Cip) * K2;
-  if (pipe) *pipe = false;
+  if (pipe) *pipe = 0;
+  bool pipe_shape = false;
   {
     int Ho, Wo;
     mt_conv_out_hw(d, &Ho, &Wo);
@@ -629,6 +634,7 @@ static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, 
     const long bb = d->transposed ? (long)d->N * Ho * Wo * Cop * esz(d->dtype) : (long)d->N * d->H * d->W * Cip * esz(d->dtype);
     const int cb = d->transposed ? Cop : Cip;
     if (mt_wgrad_pipe_ok(d->dtype, rows, cb / V, ab, bb)) {
+      pipe_shape = true;
       const int tiles = (rows / 256) * (cols / 256);
       // one round of 256 blocks; two or four rounds when a split would not fit the per-block pixel-offset table
       for (int rounds = 1; rounds <= 4; rounds *= 2) {
@@ -639,10 +645,21 @@ static void wgrad_split(const mt_conv_desc* d, int M, int* nsplit, int* mchunk, 
         if (mc <= mt_wgrad_pipe_max_chunk()) {
           *mchunk = mc;
           *nsplit = cdiv(M, mc);
-          if (pipe) *pipe = true;
+          if (pipe) *pipe = 1;
           return;
         }
       }
+    }
+  }
+  if (!pipe_shape && d->kh == 3 && d->kw == 3 && d->pad == 1 && M == wgrad_pixels(d)) {
+    WgradParams p;
+    wgrad_params(d, nullptr, nullptr, &p);
+    int ns = 0, rs = 0;
+    if (mt_wgrad_rows_plan(d->dtype, p, &ns, &rs)) {
+      *nsplit = ns;
+      *mchunk = rs;
+      if (pipe) *pipe = 2;
+      return;
     }
   }
   const int tiles = cdiv(rows, 128) * cdiv(cols, 128);
@@ -755,9 +772,10 @@ extern "C" int mt_conv_bwd_weight_partial(const mt_conv_desc* d, const void* x, 
   wgrad_params(d, x, dy, &p);
   p.out = (float*)ws;
   int nsplit;
-  bool pipe;
+  int pipe;
   wgrad_split(d, p.M, &nsplit, &p.mchunk, &pipe);
-  p.ntiles = pipe ? -1 : 0;       // tells mt_launch_wgrad which tiling the split was made for
+  p.ntiles = -pipe;               // tells mt_launch_wgrad which kernel the split was made for (-1 ping-pong, -2 row walker)
+  if (pipe == 2) { p.rows_rs = p.mchunk; p.mchunk = 0; }
   if (mt_launch_wgrad(d->dtype, p, nsplit, s)) return 2;
   *nslabs = nsplit;
   return 0;

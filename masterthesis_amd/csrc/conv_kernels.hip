@@ -979,6 +979,7 @@ int mt_launch_wgrad(int dtype, const WgradParams& pin, int nsplit, hipStream_t s
   p.b_bytes = (unsigned)((size_t)pin.N * pin.Hi * pin.Wi * pin.Cbb);
   const int V = dtype == MT_BF16 ? 8 : 4;
   const int ncols = p.nchunks * V;
+  if (p.ntiles == -2) return mt_launch_wgrad_rows(p, nsplit, s);      // ... for the accumulator-stationary row walker
   if (p.ntiles < 0) {          // the caller's split was made for the 256x256 ping-pong kernel
     p.ntiles = (p.CaRows / 256) * (ncols / 256);
     return mt_launch_wgrad_pipe(p, nsplit, s);

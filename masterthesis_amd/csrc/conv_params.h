@@ -86,6 +86,7 @@ struct WgradParams {
   int pad_mode;
   int mchunk;      // pixels per split
   int ntiles;      // output tiles (128x128) per split; grid = ntiles * nsplit blocks
+  int rows_rs, rows_sps;   // wgrad_rows_kernel only: output rows per split, splits per 32-pixel column strip
   short dh[MT_MAX_TAPS];
   short dw[MT_MAX_TAPS];
   // grouped launch (wgrad_pipe_kernel only): ngroup > 1 problems of this geometry in one grid, blocks = ngroup * ntiles * nsplit;
@@ -125,6 +126,10 @@ int mt_wgrad_pipe_max_chunk_compact();
 bool mt_wgrad_pipe_compact8_ok(const WgradParams& p);
 int mt_wgrad_pipe_max_chunk_compact8();
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s);
+// accumulator-stationary variant for 3x3 / pad 1 layers (wgrad_rows_kernel.hip): plan = "does it take the problem, with how many
+// slabs and output rows per split" (geometry only)
+bool mt_wgrad_rows_plan(int dtype, const WgradParams& p, int* nsplit, int* rs);
+int mt_launch_wgrad_rows(const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
 // one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch
 struct PackEntry {

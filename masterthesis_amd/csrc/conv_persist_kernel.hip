@@ -444,8 +444,10 @@ long mt_pipe_patch_launches();      // conv_pipe_patch_kernel.hip
 int mt_pipe_patch_enable(int on);
 long mt_wsreg_launches();           // conv_wsreg_kernel.hip
 int mt_wsreg_enable(int on);
+long mt_wgrad_rows_launches();      // wgrad_rows_kernel.hip
+int mt_wgrad_rows_enable(int on);
 extern "C" long mt_kernel_variant_launches(int which) {
-  return which == 0 ? g_persist_launches : (which == 1 ? mt_stem_launches() : (which == 2 ? mt_patch_launches() : (which == 3 ? mt_pipe_patch_launches() : (which == 4 ? mt_wsreg_launches() : -1))));
+  return which == 0 ? g_persist_launches : (which == 1 ? mt_stem_launches() : (which == 2 ? mt_patch_launches() : (which == 3 ? mt_pipe_patch_launches() : (which == 4 ? mt_wsreg_launches() : (which == 5 ? mt_wgrad_rows_launches() : -1)))));
 }
 static long g_variant_epoch = 0;
 extern "C" long mt_kernel_variant_epoch(void) { return g_variant_epoch; }
@@ -455,6 +457,7 @@ extern "C" int mt_kernel_variant_enable(int which, int enable) {
   if (which == 2) return mt_patch_enable(enable);
   if (which == 3) return mt_pipe_patch_enable(enable != 0);
   if (which == 4) return mt_wsreg_enable(enable != 0);
+  if (which == 5) return mt_wgrad_rows_enable(enable != 0);
   if (which != 0) return -1;
   const int prev = persist_enabled();
   g_persist_on = enable != 0;

@@ -1,0 +1,99 @@
+"""The accumulator-stationary weight gradient of round 4 (csrc/wgrad_rows_kernel.hip: a workgroup keeps a 64 x 9 x 64 block of dW
+in registers, one wave per filter tap, and walks down a 32-pixel column strip with the input rows in an LDS ring) against the fp32
+CPU reference of the op and against the 128 x 128 tile kernel it replaces.  Shapes are the 3x3 layers between the stem and the
+256-channel bottleneck (reference networks.py:33,248; blocks.py:73,93-119): stride 1 and stride 2, reflection / zero padding, the
+transposed convolutions (operand roles swapped), several channel blocks per operand, a row split that does not divide the map
+height.  Every case asserts that its weight gradient really ran on the new kernel (mt_kernel_variant_launches(5))."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_persist_gpu import case_seed
+
+pytestmark = pytest.mark.gpu
+
+# name, kind, N, Ci, H, W, Co, stride, pad_mode
+CASES = [
+    ("s1_64_64_reflect", "conv", 8, 64, 128, 128, 64, 1, "reflect"),
+    ("s1_64_128_reflect", "conv", 4, 64, 128, 128, 128, 1, "reflect"),
+    ("s1_128_128_zero", "conv", 8, 128, 64, 64, 128, 1, "zero"),
+    ("s1_128_256_reflect", "conv", 8, 128, 64, 64, 256, 1, "reflect"),
+    ("s1_64_64_zero_ragged_rows", "conv", 24, 64, 104, 64, 64, 1, "zero"),
+    ("s1_64_64_reflect_ragged_rows", "conv", 24, 64, 104, 64, 64, 1, "reflect"),
+    ("s2_64_128_reflect", "conv", 16, 64, 128, 128, 128, 2, "reflect"),
+    ("s2_128_256_zero", "conv", 16, 128, 64, 64, 256, 2, "zero"),
+    ("s2_64_128_zero_wide", "conv", 8, 64, 128, 256, 128, 2, "zero"),
+    ("convT_128_64", "convT", 16, 128, 64, 64, 64, 2, "zero"),
+    ("convT_256_128", "convT", 16, 256, 32, 32, 128, 2, "zero"),
+]
+
+
+def _reference(case, x, w, gy):
+    name, kind, N, Ci, H, W, Co, stride, pad_mode = case
+    wr = w.clone().requires_grad_()
+    if kind == "conv":
+        xp = F.pad(x, (1, 1, 1, 1), mode="reflect") if pad_mode == "reflect" else F.pad(x, (1, 1, 1, 1))
+        y = F.conv2d(xp, wr, None, stride=stride)
+    else:
+        y = F.conv_transpose2d(x, wr, None, stride=stride, padding=1, output_padding=1)
+    y.backward(gy)
+    return wr.grad
+
+
+def _run(ops, lib, case, dev):
+    name, kind, N, Ci, H, W, Co, stride, pad_mode = case
+    g = torch.Generator().manual_seed(case_seed(name))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    wshape = (Co, Ci, 3, 3) if kind == "conv" else (Ci, Co, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * (Ci * 9) ** -0.5).bfloat16().float()
+    xd = x.to(dev)
+    wd = w.to(dev).requires_grad_()
+    if kind == "conv":
+        y = ops.conv2d(xd, wd, None, stride=stride, pad=1, pad_mode=pad_mode)
+    else:
+        y = ops.conv_transpose2d(xd, wd, None, stride=stride, pad=1, out_pad=1)
+    gy = torch.randn(*y.shape, generator=g).bfloat16().float()
+    n0 = lib.mt_kernel_variant_launches(5)
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    n1 = lib.mt_kernel_variant_launches(5)
+    return (x, w, gy), wd.grad.detach().float().cpu(), n1 - n0
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_row_walker_weight_gradient_matches_reference_and_tile_kernel(case, hip_device):
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = L.load()
+    prev = lib.mt_kernel_variant_enable(5, 1)
+    try:
+        (x, w, gy), dw1, used = _run(ops, lib, case, hip_device)
+        assert used == 1, f"weight-gradient launches on the row walker: {used}"
+        lib.mt_kernel_variant_enable(5, 0)
+        _, dw0, unused = _run(ops, lib, case, hip_device)
+        assert unused == 0
+    finally:
+        lib.mt_kernel_variant_enable(5, prev)
+    ref = _reference(case, x, w, gy)
+    # bf16 operands, fp32 products and sums on both sides: only the summation order differs
+    rel = ((dw1 - ref).norm() / ref.norm()).item()
+    assert rel < 2e-5, f"{case[0]}: rel L2 {rel:.3e} to the fp32 CPU reference"
+    worst = ((dw1 - ref).abs().max() / ref.abs().max()).item()
+    assert worst < 2e-4, f"{case[0]}: max error {worst:.3e} of the largest gradient element"
+    rel0 = ((dw1 - dw0).norm() / dw0.norm()).item()
+    assert rel0 < 2e-5, f"{case[0]}: rel L2 {rel0:.3e} to the tile kernel"
+
+
+def test_row_walker_declines_what_it_cannot_walk(hip_device):
+    """4x4 windows, maps narrower than a 32-pixel strip and channel counts off the 64-wide blocks keep the tile kernels"""
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = L.load()
+    dev = hip_device
+    for (N, Ci, H, W, Co, k, s, p) in [(16, 64, 64, 64, 128, 4, 2, 1), (64, 256, 16, 16, 256, 3, 1, 1), (16, 48, 64, 64, 64, 3, 1, 1)]:
+        x = torch.randn(N, Ci, H, W, device=dev)
+        w = torch.randn(Co, Ci, k, k, device=dev, requires_grad=True)
+        n0 = lib.mt_kernel_variant_launches(5)
+        ops.conv2d(x, w, None, stride=s, pad=p).sum().backward()
+        assert lib.mt_kernel_variant_launches(5) == n0
+        assert torch.isfinite(w.grad).all()
