@@ -69,7 +69,9 @@ int mt_version(void);
  * 2 patch-resident gather-GEMM (conv_patch_kernel.hip: stride-1 gathers with 1 or 4 phases whose pixel tile's input
  *   patch stays in LDS; same values up to fp32 summation order -- its K loop walks channel slices first),
  * 3 the 256x256 ping-pong gather-GEMM with a patch-resident pixel operand (conv_pipe_patch_kernel.hip; bit-identical to
- *   the ring kernel it replaces: same fragments, same accumulation order) */
+ *   the ring kernel it replaces: same fragments, same accumulation order),
+ * 4 the weight-stationary gather-GEMM of the short-K layers (conv_wsreg_kernel.hip),
+ * 5 the accumulator-stationary weight gradient of the 3x3 layers (wgrad_rows_kernel.hip; same values up to fp32 summation order) */
 long mt_kernel_variant_launches(int which);
 /* switch such a variant off / on again (tests compare it bit for bit with the kernel it replaces; both are
  * results-identical by construction); returns the previous setting.  MT_IGEMM_PERSIST=0 in the environment disables
@@ -176,6 +178,16 @@ int mt_conv_bwd_weight_finish_multi(int n, const mt_conv_desc* descs, const void
  * and ONE mt_conv_bwd_weight_finish(d_any, ws, total slabs, dw, accumulate) sums them: one pass over the gradient instead of one
  * per use. */
 size_t mt_conv_bwd_weight_slab_bytes(const mt_conv_desc* d);
+/* Weight gradients of SEVERAL 3x3 / pad 1 layers (stride 1 or 2, transposed or not, 64-wide channel blocks, maps whole 32-pixel
+ * strips wide: mt_conv_bwd_weight_rows_ok) in shared launches of the accumulator-stationary kernel (wgrad_rows_kernel.hip; replaces
+ * the per-layer weight-gradient GEMMs autograd would run for nn.Conv2d / nn.ConvTranspose2d of blocks.py:10-91, networks.py:33,248):
+ * a layer alone fills the chip only by cutting its pixel reduction ~256 ways; the eligible layers of a whole backward pass share
+ * the compute units instead (one launch per stride class, one batched slab sum).  dw[i] (+)= the weight gradient of problem i in
+ * the reference layout; problems that accumulate into the SAME dw must be adjacent.  n <= 64.  bf16 storage only. */
+int mt_conv_bwd_weight_rows_ok(const mt_conv_desc* d);
+size_t mt_conv_bwd_weight_rows_multi_ws_bytes(int n, const mt_conv_desc* descs);
+int mt_conv_bwd_weight_rows_multi(int n, const mt_conv_desc* descs, const void* const* x, const void* const* dy, float* const* dw,
+                                  void* ws, size_t ws_bytes, int accumulate, mt_stream_t s);
 
 /* ---- nn.Linear fp32 (K17): networks.py:127-128,256-261, norm.py:27 ------------------ */
 int mt_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,

@@ -72,6 +72,9 @@ SIGNATURES = {
     "mt_conv_bwd_weight_finish": (_i, [_dp, _p, _i, _p, _i, _p]),
     "mt_conv_bwd_weight_finish_multi": (_i, [_i, _p, _p, _p, _p, _i, _p]),
     "mt_conv_bwd_weight_slab_bytes": (_z, [_dp]),
+    "mt_conv_bwd_weight_rows_ok": (_i, [_dp]),
+    "mt_conv_bwd_weight_rows_multi_ws_bytes": (_z, [_i, _p]),
+    "mt_conv_bwd_weight_rows_multi": (_i, [_i, _p, _p, _p, _p, _p, _z, _i, _p]),
     "mt_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mt_conv_fwd_stats_fused": (_i, [_dp]),

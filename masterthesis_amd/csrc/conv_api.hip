@@ -857,6 +857,94 @@ extern "C" int mt_conv_bwd_weight(const mt_conv_desc* d, const void* x, const vo
   return dw != nullptr ? mt_conv_bwd_weight_finish(d, ws, nslabs, dw, accumulate, st) : 0;
 }
 
+// ---- weight gradients of several 3x3 layers in shared launches of the row walker (round 4; wgrad_rows_kernel.hip) ------------
+// A layer of the encoders / the decoder alone cannot fill 256 compute units without cutting its pixel reduction ~256 ways: 38 MB
+// of fp32 slabs written and read back for a 150-600 KB gradient, and a prologue / epilogue per 30-60 k-steps.  Weight gradients
+// are leaves of the backward pass, so the caller parks them and hands ALL of a pass's eligible layers over at once: one launch
+// per stride class walks every problem with a share of the chip in proportion to its work (~25 slabs per layer for ten layers),
+// and one batched slab sum adds them into the gradients.  Entries that accumulate into the SAME dw must be adjacent: their
+// slabs are summed by one entry of the batched sum.
+#define MT_ROWS_MULTI_MAX 64
+extern "C" int mt_conv_bwd_weight_rows_ok(const mt_conv_desc* d) {
+  if (d == nullptr || d->kh != 3 || d->kw != 3 || d->pad != 1 || d->stride < 1 || d->stride > 2) return 0;
+  if (mt_stem_wgrad_ok(d) || mt_pointwise_small(d)) return 0;
+  WgradParams p;
+  wgrad_params(d, nullptr, nullptr, &p);
+  if (mt_wgrad_pipe_ok(d->dtype, p.CaRows, p.cpc, (long)p.M * p.Cab, (long)p.N * p.Hi * p.Wi * p.Cbb)) return 0;   // ping-pong shapes
+  return mt_wgrad_rows_ok(d->dtype, p) ? 1 : 0;
+}
+static int rows_multi_plan(int n, const mt_conv_desc* descs, WgradParams* ps, int* nsplit, int* rps, size_t* offs, size_t* total) {
+  MT_CHECK(n >= 1 && n <= MT_ROWS_MULTI_MAX && descs != nullptr, "conv_bwd_weight_rows_multi: %d problems (1..%d)", n, MT_ROWS_MULTI_MAX);
+  for (int i = 0; i < n; i++) {
+    if (check_desc(&descs[i])) return 1;
+    MT_CHECK(mt_conv_bwd_weight_rows_ok(&descs[i]), "conv_bwd_weight_rows_multi: problem %d is not a row-walker shape", i);
+    wgrad_params(&descs[i], nullptr, nullptr, &ps[i]);
+  }
+  mt_wgrad_rows_plan_multi(n, ps, nsplit, rps);
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    offs[i] = off;
+    off += (size_t)nsplit[i] * mt_padc(descs[i].Ci) * mt_padc(descs[i].Co) * 9 * sizeof(float);
+  }
+  *total = off;
+  return 0;
+}
+extern "C" size_t mt_conv_bwd_weight_rows_multi_ws_bytes(int n, const mt_conv_desc* descs) {
+  WgradParams ps[MT_ROWS_MULTI_MAX];
+  int nsplit[MT_ROWS_MULTI_MAX], rps[MT_ROWS_MULTI_MAX];
+  size_t offs[MT_ROWS_MULTI_MAX], total = 0;
+  if (rows_multi_plan(n, descs, ps, nsplit, rps, offs, &total)) return 0;
+  return total;
+}
+extern "C" int mt_conv_bwd_weight_rows_multi(int n, const mt_conv_desc* descs, const void* const* x, const void* const* dy,
+                                             float* const* dw, void* ws, size_t ws_bytes, int accumulate, mt_stream_t st) {
+  WgradParams ps[MT_ROWS_MULTI_MAX];
+  int nsplit[MT_ROWS_MULTI_MAX], rps[MT_ROWS_MULTI_MAX];
+  size_t offs[MT_ROWS_MULTI_MAX], total = 0;
+  if (rows_multi_plan(n, descs, ps, nsplit, rps, offs, &total)) return 1;
+  MT_CHECK(x && dy && dw && ws != nullptr && ws_bytes >= total, "conv_bwd_weight_rows_multi: workspace too small / null argument");
+  hipStream_t s = (hipStream_t)st;
+  for (int i = 0; i < n; i++) {
+    MT_CHECK(x[i] && dy[i] && dw[i], "conv_bwd_weight_rows_multi: problem %d has a null operand", i);
+    WgradParams g;
+    wgrad_params(&descs[i], x[i], dy[i], &g);
+    ps[i].a = g.a; ps[i].b = g.b;
+    ps[i].out = (float*)((char*)ws + offs[i]);
+  }
+  if (mt_launch_wgrad_rows_multi(n, ps, nsplit, rps, s)) return 2;
+  // one slab sum per gradient tensor: adjacent problems of one dw (uses of one weight: same slab form) are one entry
+  const float* src[MT_UNPACK_MULTI_MAX];
+  float* dst[MT_UNPACK_MULTI_MAX];
+  PackParams us[MT_UNPACK_MULTI_MAX];
+  int ns[MT_UNPACK_MULTI_MAX];
+  long slabs[MT_UNPACK_MULTI_MAX];
+  int k = 0;
+  for (int i = 0; i < n;) {
+    int j = i, tot = 0;
+    const long slab = (long)mt_padc(descs[i].Ci) * mt_padc(descs[i].Co) * 9;
+    for (; j < n && dw[j] == dw[i]; j++) {
+      MT_CHECK((long)mt_padc(descs[j].Ci) * mt_padc(descs[j].Co) * 9 == slab && descs[j].transposed == descs[i].transposed &&
+               descs[j].Ci == descs[i].Ci && descs[j].Co == descs[i].Co,
+               "conv_bwd_weight_rows_multi: problems %d and %d share a gradient but not a weight shape", i, j);
+      tot += nsplit[j];
+    }
+    PackParams u;
+    bwd_weight_unpack_params(&descs[i], &u);
+    if (!mt_unpack_multi_ok(u)) {
+      if (mt_launch_unpack((const float*)((char*)ws + offs[i]), dw[i], u, tot, slab, accumulate, s)) return 2;
+    } else {
+      src[k] = (const float*)((char*)ws + offs[i]); dst[k] = dw[i]; us[k] = u; ns[k] = tot; slabs[k] = slab;
+      if (++k == MT_UNPACK_MULTI_MAX) {
+        if (mt_launch_unpack_multi(k, src, dst, us, ns, slabs, accumulate, s)) return 2;
+        k = 0;
+      }
+    }
+    i = j;
+  }
+  if (k > 0 && mt_launch_unpack_multi(k, src, dst, us, ns, slabs, accumulate, s)) return 2;
+  return 0;
+}
+
 // ---- grouped weight gradient (round 3) ----------------------------------------------------------------------------------
 // The 256x256 ping-pong weight gradient splits the pixel reduction so that (tiles x splits) fills the 256 CUs: the dominant
 // layer (9 tiles) runs 28 splits, i.e. it writes 28 fp32 slabs of the whole gradient (66 MB) and the slab sum reads them

@@ -86,7 +86,7 @@ struct WgradParams {
   int pad_mode;
   int mchunk;      // pixels per split
   int ntiles;      // output tiles (128x128) per split; grid = ntiles * nsplit blocks
-  int rows_rs, rows_sps;   // wgrad_rows_kernel only: output rows per split, splits per 32-pixel column strip
+  int rows_rs;     // wgrad_rows_kernel only: k-steps (strip, output row) per split
   short dh[MT_MAX_TAPS];
   short dw[MT_MAX_TAPS];
   // grouped launch (wgrad_pipe_kernel only): ngroup > 1 problems of this geometry in one grid, blocks = ngroup * ntiles * nsplit;
@@ -126,9 +126,13 @@ int mt_wgrad_pipe_max_chunk_compact();
 bool mt_wgrad_pipe_compact8_ok(const WgradParams& p);
 int mt_wgrad_pipe_max_chunk_compact8();
 int mt_launch_wgrad_pipe(const WgradParams& p, int nsplit, hipStream_t s);
-// accumulator-stationary variant for 3x3 / pad 1 layers (wgrad_rows_kernel.hip): plan = "does it take the problem, with how many
-// slabs and output rows per split" (geometry only)
+// accumulator-stationary variant for 3x3 / pad 1 layers (wgrad_rows_kernel.hip).  ok: geometry check; plan: "is a launch of its
+// own worth it, with how many slabs and k-steps per split"; *_multi: several problems (ps[i].a / .b / .out set) sharing launches
+#define MT_WR_MAXP 24
+bool mt_wgrad_rows_ok(int dtype, const WgradParams& p);
 bool mt_wgrad_rows_plan(int dtype, const WgradParams& p, int* nsplit, int* rs);
+void mt_wgrad_rows_plan_multi(int n, const WgradParams* ps, int* nsplit, int* rps);
+int mt_launch_wgrad_rows_multi(int n, const WgradParams* ps, const int* nsplit, const int* rps, hipStream_t s);
 int mt_launch_wgrad_rows(const WgradParams& p, int nsplit, hipStream_t s);
 int mt_launch_pack(int dtype, const float* w, void* out, const PackParams& p, hipStream_t s);
 // one entry of a batched weight pack (mt_conv_pack_multi_*): a whole network's weights in ONE launch

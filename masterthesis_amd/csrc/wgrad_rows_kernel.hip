@@ -24,6 +24,7 @@
 // mt_wgrad_rows_plan; MT_WGRAD_ROWS=0 / mt_kernel_variant_enable(5, 0) switch it off.  Parity: tests/test_wgrad_rows_gpu.py.
 #include "conv_device.h"
 #include <stdlib.h>
+#include <string.h>
 
 constexpr int WR_D = 4;                     // ticks of copies in flight
 constexpr int WR_NA = WR_D + 1;             // ring slots of the dense operand (4 KiB each)
@@ -43,6 +44,25 @@ template <int S> struct WrGeom {
   static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
 };
 
+// one weight-gradient problem of a launch (several layers' problems share a launch: mt_launch_wgrad_rows_multi)
+struct WrProb {
+  const char* a;            // dense operand, pixel-major [N Ho Wo][Cab bytes]
+  const char* b;            // gathered operand, NHWC [N][Hi][Wi][Cbb bytes], Hi = S Ho, Wi = S Wo
+  float* out;               // fp32 slabs [nsplit][64 nca][9][64 ncb]
+  unsigned a_bytes, b_bytes;
+  int Ho, Wo, Hi, Wi;
+  int Cab, Cbb;
+  int nca, ncb;             // 64-channel blocks of the two operands
+  int rows;                 // k-steps = strips x Ho (strip-major)
+  int rps;                  // k-steps per split
+  int blk0, nblk;           // first block of the launch (a multiple of 8), blocks = nsplit x nca x ncb
+  int reflect;
+};
+struct WrMulti {
+  int n;
+  WrProb p[MT_WR_MAXP];
+};
+
 template <int OFF>
 __device__ __forceinline__ s16x4 wr_tr16(unsigned addr) {     // (inline asm: see wgrad_pipe_kernel.hip)
   s16x4 r;
@@ -51,8 +71,8 @@ __device__ __forceinline__ s16x4 wr_tr16(unsigned addr) {     // (inline asm: se
 }
 __device__ __forceinline__ int wr_swz(int e) { return e ^ (((e >> 3) & 1) << 2); }
 
-template <int S, bool REFLECT>
-__global__ __launch_bounds__(576) void wgrad_rows_kernel(const WgradParams p) {
+template <int S>
+__global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   using G = WrGeom<S>;
   constexpr unsigned OOB = 0x80000000u;
   static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -66,107 +86,34 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WgradParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = filter tap
   const int dh = wv / 3 - 1, dwo = wv % 3;                         // tap row offset, tap column offset + 1
 
-  // ---- which block of dW, which strip, which rows ----
-  const int nca = p.CaRows >> 6, ncb = (p.cpc * 8) >> 6, nblk = nca * ncb;
-  const int vid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = vid / nblk, rest = vid - split * nblk;
+  // ---- which problem of the launch (blocks of a problem are consecutive, blk0 a multiple of 8), which block of its dW, which
+  // range of its k-steps (k-step = (strip, output row), strip-major) ----
+  int pi = 0;
+  for (int i = 1; i < m.n; i++) pi = (int)blockIdx.x >= m.p[i].blk0 ? i : pi;
+  const char* const pa = m.p[pi].a;
+  const char* const pb = m.p[pi].b;
+  float* const pout = m.p[pi].out;
+  const unsigned a_bytes = m.p[pi].a_bytes, b_bytes = m.p[pi].b_bytes;
+  const int Ho = m.p[pi].Ho, Wo = m.p[pi].Wo, Hi = m.p[pi].Hi, Wi = m.p[pi].Wi;
+  const unsigned cab_b = (unsigned)m.p[pi].Cab, cbb_b = (unsigned)m.p[pi].Cbb;
+  const int nca = m.p[pi].nca, ncb = m.p[pi].ncb, rows = m.p[pi].rows, rps = m.p[pi].rps;
+  const int nblk = m.p[pi].nblk;
+  const bool refl = m.p[pi].reflect != 0;
+  const int vid = xcd_remap((int)blockIdx.x - m.p[pi].blk0, (nblk + 7) & ~7);
+  if (vid >= nblk) return;
+  const int nb = nca * ncb;
+  const int split = vid / nb, rest = vid - split * nb;
   const int cab = rest % nca, cbb = rest / nca;
-  const int sps = p.rows_sps, wblocks = p.Wo >> 5;
-  const int strip = split / sps, part = split - strip * sps;
-  const int n = strip / wblocks, w0 = (strip - n * wblocks) << 5;
-  const int h0 = part * p.rows_rs;
-  const int h1 = min(p.Ho, h0 + p.rows_rs);
-  const int T = h1 - h0 + G::WARM;                                 // ticks (host: h0 < Ho)
+  const int wblocks = Wo >> 5;
+  const int gbeg = split * rps;
+  const int gend = min(rows, gbeg + rps);                          // (host: gbeg < rows)
 
-  // ---- copy duties of this wave: copy q = wv + 9 e of the tick's NCOPY (q < 4: plane q of the dense segment; else row (q-4) / CB,
-  // KiB (q-4) % CB of a gathered row segment; q >= NCOPY: dummy) ----
-  unsigned loff[G::CPW];          // per-lane source offset inside the row (bytes), or OOB
-  int ckind[G::CPW];              // 0 dense, 1 gathered, 2 dummy (wave-uniform)
-  int crow[G::CPW];               // gathered: which of the tick's S rows
-  unsigned cdst[G::CPW];          // destination offset inside the ring slot
-#pragma unroll
-  for (int e = 0; e < G::CPW; e++) {
-    const int q = wv + 9 * e;
-    if (q < 4) {
-      const int pos = lane >> 1, half = lane & 1, k = wr_swz(pos);
-      ckind[e] = 0; crow[e] = 0; cdst[e] = (unsigned)q * WR_APLANE;
-      loff[e] = (unsigned)k * (unsigned)p.Cab + (unsigned)cab * 128u + (unsigned)q * 32u + (unsigned)half * 16u;
-    } else if (q < G::NCOPY) {
-      const int qb = q - 4, r = qb / G::CB, i = qb - r * G::CB;
-      const int o = i * 1024 + lane * 16;
-      const int par = S == 2 ? o / (4 * WR_BPLANE) : 0;
-      const int f = (o - par * 4 * WR_BPLANE) / WR_BPLANE;
-      const int rem = o - par * 4 * WR_BPLANE - f * WR_BPLANE;
-      const int hx = wr_swz(rem >> 5), half = (rem >> 4) & 1;
-      const int c = S == 2 ? 2 * hx + par : hx;                    // segment-relative input pixel (0 = the left halo pixel)
-      bool ok = c < (S == 2 ? 65 : 34);
-      int wi = S * w0 - 1 + c;
-      if constexpr (REFLECT) {
-        wi = wi < 0 ? -wi : wi;
-        wi = wi >= p.Wi ? 2 * (p.Wi - 1) - wi : wi;
-        ok = ok && wi >= 0 && wi < p.Wi;
-      } else {
-        ok = ok && (unsigned)wi < (unsigned)p.Wi;
-      }
-      ckind[e] = 1; crow[e] = r; cdst[e] = (unsigned)i * 1024u;
-      loff[e] = ok ? (unsigned)wi * (unsigned)p.Cbb + (unsigned)cbb * 128u + (unsigned)f * 32u + (unsigned)half * 16u : OOB;
-    } else {
-      ckind[e] = 2; crow[e] = 0; cdst[e] = 0; loff[e] = OOB;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
-  const unsigned cab_b = (unsigned)p.Cab, cbb_b = (unsigned)p.Cbb;
-  const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi;
-
-  int l_tick = 0, l_aslot = 0, l_bslot = 0;          // the next tick to load and the ring slots it fills
-  auto issue_tick = [&]() {
-    const bool live = l_tick < T;
-#pragma unroll
-    for (int e = 0; e < G::CPW; e++) {
-      if (ckind[e] == 0) {
-        const int h = h0 + l_tick - G::WARM;
-        const bool ok = live && l_tick >= G::WARM;                 // (h < h1 follows from l_tick < T)
-        const unsigned base = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
-        const unsigned vo = ok ? base + loff[e] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::A_OFF + l_aslot * WR_ASLOT + cdst[e]), 16, vo, 0, 0, 0);
-      } else if (ckind[e] == 1) {
-        int hi = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
-        bool ok = live;
-        if constexpr (REFLECT) {
-          hi = hi < 0 ? -hi : hi;
-          hi = hi >= Hi ? 2 * (Hi - 1) - hi : hi;
-          ok = ok && hi >= 0 && hi < Hi;
-        } else {
-          ok = ok && (unsigned)hi < (unsigned)Hi;
-        }
-        const unsigned base = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
-        const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
-        int bs = l_bslot + crow[e];
-        bs = bs >= G::NB ? bs - G::NB : bs;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lds0 + G::B_OFF + bs * G::BSLOT + cdst[e]), 16, vo, 0, 0, 0);
-      } else {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::DUMMY_OFF), 16, OOB, 0, 0, 0);
-      }
-    }
-    l_tick++;
-    l_aslot = l_aslot + 1 == WR_NA ? 0 : l_aslot + 1;
-    l_bslot += S;
-    l_bslot = l_bslot >= G::NB ? l_bslot - G::NB : l_bslot;
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < WR_D; s++) issue_tick();
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, b_bytes, 0x00020000);
 
   // ---- fragment addresses: lane (g, qq, pp) supplies [entry 8 g + qq (+ 4)][channels 4 pp .. 4 pp + 3] of a fragment plane ----
-  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-  const int kk = 8 * g + qq;
+  const int fgq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int kk = 8 * fgq + qq;
   const unsigned aoff0 = (unsigned)(wr_swz(kk) * 32 + pp * 8), aoff1 = (unsigned)(wr_swz(kk + 4) * 32 + pp * 8);
   unsigned boff0, boff1;
   if constexpr (S == 1) {
@@ -177,56 +124,153 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WgradParams p) {
     boff0 = (unsigned)(par * 4 * WR_BPLANE + wr_swz(hx) * 32 + pp * 8);
     boff1 = (unsigned)(par * 4 * WR_BPLANE + wr_swz(hx + 4) * 32 + pp * 8);
   }
-  // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)
-  int c_aslot = 0;
-  int c_bslot = (S == 1 ? dh - 1 : dh) + G::NB;
-  c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
 
-  for (int j = 0; j < T; j++) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * G::CPW) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                  // every wave's copies of tick j have landed; tick j - 1 has been read
-    __builtin_amdgcn_sched_barrier(0);
-    issue_tick();
-    __builtin_amdgcn_sched_barrier(0);
-    if (j >= G::WARM) {
-      const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
-      const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
-      bf16x8 af[4], bf[4];
-#define WR_FRAG(dst, base, o0, o1, OFF)                                                                     \
-      {                                                                                                     \
-        const s16x4 lo = wr_tr16<OFF>(base + o0), hi = wr_tr16<OFF>(base + o1);                             \
-        dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));          \
-      }
-      WR_FRAG(af[0], sa, aoff0, aoff1, 0 * WR_APLANE);
-      WR_FRAG(af[1], sa, aoff0, aoff1, 1 * WR_APLANE);
-      WR_FRAG(af[2], sa, aoff0, aoff1, 2 * WR_APLANE);
-      WR_FRAG(af[3], sa, aoff0, aoff1, 3 * WR_APLANE);
-      WR_FRAG(bf[0], sb, boff0, boff1, 0 * WR_BPLANE);
-      WR_FRAG(bf[1], sb, boff0, boff1, 1 * WR_BPLANE);
-      WR_FRAG(bf[2], sb, boff0, boff1, 2 * WR_BPLANE);
-      WR_FRAG(bf[3], sb, boff0, boff1, 3 * WR_BPLANE);
-#undef WR_FRAG
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // gathered operand as MFMA A: a lane ends with 4 consecutive columns of one a-channel (16-byte slab stores)
+  f32x4 acc[4][4];
 #pragma unroll
-      for (int a = 0; a < 4; a++)
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    c_aslot = c_aslot + 1 == WR_NA ? 0 : c_aslot + 1;
-    c_bslot += S;
-    c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // copy duties of this wave: copy q = wv + 9 e of a tick's NCOPY (q < 4: plane q of the dense segment; else row (q-4) / CB,
+  // KiB (q-4) % CB of a gathered row segment; q >= NCOPY: dummy): kind / row / destination are wave-uniform
+  int ckind[G::CPW], crow[G::CPW];
+  unsigned cdst[G::CPW];
+#pragma unroll
+  for (int e = 0; e < G::CPW; e++) {
+    const int q = wv + 9 * e;
+    if (q < 4) { ckind[e] = 0; crow[e] = 0; cdst[e] = (unsigned)q * WR_APLANE; }
+    else if (q < G::NCOPY) { const int qb = q - 4; ckind[e] = 1; crow[e] = qb / G::CB; cdst[e] = (unsigned)(qb - crow[e] * G::CB) * 1024u; }
+    else { ckind[e] = 2; crow[e] = 0; cdst[e] = 0; }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (all-zero) copies must have landed before the wave exits
+
+  for (int gpos = gbeg; gpos < gend;) {
+    // ---- one run of consecutive output rows h0 .. h1 - 1 of one 32-pixel column strip ----
+    const int strip = gpos / Ho, h0 = gpos - strip * Ho;
+    const int h1 = min(Ho, h0 + (gend - gpos));
+    const int n = strip / wblocks, w0 = (strip - n * wblocks) << 5;
+    const int T = h1 - h0 + G::WARM;                               // ticks
+    gpos += h1 - h0;
+
+    unsigned loff[G::CPW];          // per-lane source offset inside the row (bytes), or OOB
+#pragma unroll
+    for (int e = 0; e < G::CPW; e++) {
+      const int q = wv + 9 * e;
+      if (q < 4) {
+        const int pos = lane >> 1, half = lane & 1, k = wr_swz(pos);
+        loff[e] = (unsigned)k * cab_b + (unsigned)cab * 128u + (unsigned)q * 32u + (unsigned)half * 16u;
+      } else if (q < G::NCOPY) {
+        const int qb = q - 4, i = qb - (qb / G::CB) * G::CB;
+        const int o = i * 1024 + lane * 16;
+        const int par = S == 2 ? o / (4 * WR_BPLANE) : 0;
+        const int f = (o - par * 4 * WR_BPLANE) / WR_BPLANE;
+        const int rem = o - par * 4 * WR_BPLANE - f * WR_BPLANE;
+        const int hx = wr_swz(rem >> 5), half = (rem >> 4) & 1;
+        const int c = S == 2 ? 2 * hx + par : hx;                  // segment-relative input pixel (0 = the left halo pixel)
+        bool ok = c < (S == 2 ? 65 : 34);
+        int wi = S * w0 - 1 + c;
+        if (refl) {
+          wi = wi < 0 ? -wi : wi;
+          wi = wi >= Wi ? 2 * (Wi - 1) - wi : wi;
+        }
+        ok = ok && (unsigned)wi < (unsigned)Wi;
+        loff[e] = ok ? (unsigned)wi * cbb_b + (unsigned)cbb * 128u + (unsigned)f * 32u + (unsigned)half * 16u : OOB;
+      } else {
+        loff[e] = OOB;
+      }
+    }
+
+    int l_tick = 0, l_aslot = 0, l_bslot = 0;          // the next tick to load and the ring slots it fills
+    auto issue_tick = [&]() {
+      const bool live = l_tick < T;
+#pragma unroll
+      for (int e = 0; e < G::CPW; e++) {
+        if (ckind[e] == 0) {
+          const int h = h0 + l_tick - G::WARM;
+          const bool ok = live && l_tick >= G::WARM;               // (h < h1 follows from l_tick < T)
+          const unsigned base = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
+          const unsigned vo = ok ? base + loff[e] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::A_OFF + l_aslot * WR_ASLOT + cdst[e]), 16, vo, 0, 0, 0);
+        } else if (ckind[e] == 1) {
+          int hi = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
+          if (refl) {
+            hi = hi < 0 ? -hi : hi;
+            hi = hi >= Hi ? 2 * (Hi - 1) - hi : hi;
+          }
+          const bool ok = live && (unsigned)hi < (unsigned)Hi;
+          const unsigned base = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
+          const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
+          int bs = l_bslot + crow[e];
+          bs = bs >= G::NB ? bs - G::NB : bs;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lds0 + G::B_OFF + bs * G::BSLOT + cdst[e]), 16, vo, 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::DUMMY_OFF), 16, OOB, 0, 0, 0);
+        }
+      }
+      l_tick++;
+      l_aslot = l_aslot + 1 == WR_NA ? 0 : l_aslot + 1;
+      l_bslot += S;
+      l_bslot = l_bslot >= G::NB ? l_bslot - G::NB : l_bslot;
+    };
+
+#pragma unroll
+    for (int s = 0; s < WR_D; s++) issue_tick();
+
+    // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)
+    int c_aslot = 0;
+    int c_bslot = (S == 1 ? dh - 1 : dh) + G::NB;
+    c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+
+    for (int j = 0; j < T; j++) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * G::CPW) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                  // every wave's copies of tick j have landed; tick j - 1 has been read
+      __builtin_amdgcn_sched_barrier(0);
+      issue_tick();
+      __builtin_amdgcn_sched_barrier(0);
+      if (j >= G::WARM) {
+        const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
+        const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
+        bf16x8 af[4], bf[4];
+#define WR_FRAG(dst, base, o0, o1, OFF)                                                                     \
+        {                                                                                                   \
+          const s16x4 lo = wr_tr16<OFF>(base + o0), hi = wr_tr16<OFF>(base + o1);                           \
+          dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));        \
+        }
+        WR_FRAG(af[0], sa, aoff0, aoff1, 0 * WR_APLANE);
+        WR_FRAG(af[1], sa, aoff0, aoff1, 1 * WR_APLANE);
+        WR_FRAG(af[2], sa, aoff0, aoff1, 2 * WR_APLANE);
+        WR_FRAG(af[3], sa, aoff0, aoff1, 3 * WR_APLANE);
+        WR_FRAG(bf[0], sb, boff0, boff1, 0 * WR_BPLANE);
+        WR_FRAG(bf[1], sb, boff0, boff1, 1 * WR_BPLANE);
+        WR_FRAG(bf[2], sb, boff0, boff1, 2 * WR_BPLANE);
+        WR_FRAG(bf[3], sb, boff0, boff1, 3 * WR_BPLANE);
+#undef WR_FRAG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // gathered operand as MFMA A: a lane ends with 4 consecutive columns of one a-channel (16-byte slab stores)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      c_aslot = c_aslot + 1 == WR_NA ? 0 : c_aslot + 1;
+      c_bslot += S;
+      c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+    }
+    // the trailing (all-zero) copies must have landed, and every wave must be done with the ring, before the next run refills it
+    // (or the wave exits)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // ---- epilogue: this workgroup's 64 x 9 x 64 block of the split's fp32 slab [CaRows][taps][Cb] ----
   const int fr = lane & 15, fg = lane >> 4;
-  const int cbt = p.cpc * 8, ncols = p.nchunks * 8;
-  float* const slab = p.out + (size_t)split * p.CaRows * ncols;
+  const int cbt = ncb * 64, ncols = 9 * cbt;
+  float* const slab = pout + (size_t)split * (size_t)(nca * 64) * ncols;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int ca = cab * 64 + a * 16 + fr;
@@ -251,9 +295,8 @@ int mt_wgrad_rows_enable(int on) {
   return prev;
 }
 
-// Does the accumulator-stationary kernel take this problem, and with which pixel split?  (geometry only: p.a / p.b / p.out unused)
-//   *nsplit = slabs; *rs = output rows per split; the kernel derives the splits per strip as ceil(Ho / rs).
-bool mt_wgrad_rows_plan(int dtype, const WgradParams& p, int* nsplit, int* rs) {
+// Does the row walker take this problem?  (geometry only: p.a / p.b / p.out unused)
+bool mt_wgrad_rows_ok(int dtype, const WgradParams& p) {
   if (!wr_enabled() || dtype != MT_BF16) return false;
   if (p.ntaps != 9 || (p.is != 1 && p.is != 2)) return false;
   for (int t = 0; t < 9; t++)
@@ -262,37 +305,94 @@ bool mt_wgrad_rows_plan(int dtype, const WgradParams& p, int* nsplit, int* rs) {
   if (p.CaRows % 64 || cb % 64 || p.Cab != p.CaRows * 2 || p.Cbb != cb * 2) return false;
   if (p.Wo % 32 || p.Hi != p.is * p.Ho || p.Wi != p.is * p.Wo || p.Hi < 2 || p.Wi < 2) return false;
   if ((double)p.M * p.Cab >= 2147483000.0 || (double)p.N * p.Hi * p.Wi * p.Cbb >= 2147483000.0) return false;
-  const int blocks = (p.CaRows / 64) * (cb / 64);
-  if (blocks > 64) return false;
-  const long strips = (long)p.N * (p.Wo / 32);
-  const long ticks = strips * p.Ho;
-  if (ticks * blocks < 256L * 16) return false;       // less than 16 ticks per compute unit: the tile kernels' splits serve it
-  const int target = 256 / blocks;                     // workgroups of one round, per channel block
-  long sps = target / strips;
-  if (sps < 1) sps = 1;
-  if (sps > p.Ho / 8) sps = p.Ho / 8 > 0 ? p.Ho / 8 : 1;
-  const int rows = (int)((p.Ho + sps - 1) / sps);
-  sps = (p.Ho + rows - 1) / rows;
-  if (strips * sps > 4096) return false;
-  *nsplit = (int)(strips * sps);
-  *rs = rows;
+  if ((p.CaRows / 64) * (cb / 64) > 64) return false;
+  if ((long)p.N * (p.Wo / 32) * p.Ho > 0x3fffffffL) return false;
+  return true;
+}
+static inline long wr_rows(const WgradParams& p) { return (long)p.N * (p.Wo / 32) * p.Ho; }
+static inline int wr_blocks(const WgradParams& p) { return (p.CaRows / 64) * (p.cpc * 8 / 64); }
+
+// Pixel splits of n problems that share launches (one launch per stride class): the 256 compute units are dealt out in proportion
+// to the problems' k-steps x channel blocks, every workgroup of a launch walks about the same number of ticks, and a problem's slab
+// count shrinks with the company it has (10 layers in one launch: ~25 slabs each instead of 256).  nsplit[i] slabs, rps[i] k-steps
+// per split.  All problems must have passed mt_wgrad_rows_ok.
+void mt_wgrad_rows_plan_multi(int n, const WgradParams* ps, int* nsplit, int* rps) {
+  for (int S = 1; S <= 2; S++) {
+    double total = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; i++)
+      if (ps[i].is == S) { total += (double)wr_rows(ps[i]) * wr_blocks(ps[i]); cnt++; }
+    if (!cnt) continue;
+    // (launches of more than MT_WR_MAXP problems are cut into chunks by the launcher; the budget is per launch)
+    const int launches = (cnt + MT_WR_MAXP - 1) / MT_WR_MAXP;
+    int budget = 256 * launches;
+    for (int round = 0; round < 16; round++) {
+      long used = 0;
+      for (int i = 0; i < n; i++) {
+        if (ps[i].is != S) continue;
+        const long rows = wr_rows(ps[i]);
+        const int nb = wr_blocks(ps[i]);
+        long w = (long)(budget * ((double)rows * nb / total));
+        long ns = w / nb;
+        if (ns < 1) ns = 1;
+        if (ns > rows / 8) ns = rows / 8 > 0 ? rows / 8 : 1;
+        const long r = (rows + ns - 1) / ns;
+        ns = (rows + r - 1) / r;
+        nsplit[i] = (int)ns;
+        rps[i] = (int)r;
+        used += ((ns * nb + 7) & ~7L);
+      }
+      if (used <= 256L * launches) break;
+      budget -= (int)(used - 256L * launches) + 1;
+      if (budget < cnt) break;
+    }
+  }
+}
+
+// single problem: is it worth a launch of its own, and with which split?  *rs = k-steps per split
+bool mt_wgrad_rows_plan(int dtype, const WgradParams& p, int* nsplit, int* rs) {
+  if (!mt_wgrad_rows_ok(dtype, p)) return false;
+  if (wr_rows(p) * wr_blocks(p) < 256L * 16) return false;      // less than 16 ticks per compute unit: the tile kernels' splits serve it
+  mt_wgrad_rows_plan_multi(1, &p, nsplit, rs);
   return true;
 }
 
-int mt_launch_wgrad_rows(const WgradParams& pin, int nsplit, hipStream_t s) {
-  WgradParams p = pin;
-  MT_CHECK(p.rows_rs > 0, "wgrad_rows: no row split");
-  p.rows_sps = (p.Ho + p.rows_rs - 1) / p.rows_rs;
-  const long strips = (long)p.N * (p.Wo / 32);
-  MT_CHECK((long)nsplit == strips * p.rows_sps, "wgrad_rows: %d splits for %ld strips x %d", nsplit, strips, p.rows_sps);
-  const int blocks = (p.CaRows / 64) * (p.cpc * 8 / 64);
-  dim3 grid((unsigned)(nsplit * blocks));
-  const bool refl = p.pad_mode == MT_PAD_REFLECT;
-#define MT_WR(S, R) hipLaunchKernelGGL((wgrad_rows_kernel<S, R>), grid, dim3(576), 0, s, p)
-  if (p.is == 1) { if (refl) MT_WR(1, true); else MT_WR(1, false); }
-  else { if (refl) MT_WR(2, true); else MT_WR(2, false); }
-#undef MT_WR
-  MT_LAUNCH_CHECK();
-  g_wr_launches++;
+// n problems (ps[i].a / .b / .out set; out = the problem's nsplit[i] slabs) in one launch per stride class and MT_WR_MAXP problems
+int mt_launch_wgrad_rows_multi(int n, const WgradParams* ps, const int* nsplit, const int* rps, hipStream_t s) {
+  for (int S = 1; S <= 2; S++) {
+    int i = 0;
+    while (i < n) {
+      WrMulti m;
+      memset(&m, 0, sizeof(m));
+      int blocks = 0;
+      for (; i < n && m.n < MT_WR_MAXP; i++) {
+        const WgradParams& p = ps[i];
+        if (p.is != S) continue;
+        MT_CHECK(nsplit[i] > 0 && rps[i] > 0 && (long)nsplit[i] * rps[i] >= wr_rows(p) && (long)(nsplit[i] - 1) * rps[i] < wr_rows(p),
+                 "wgrad_rows: split %d x %d does not cover %ld k-steps", nsplit[i], rps[i], wr_rows(p));
+        WrProb& q = m.p[m.n++];
+        q.a = p.a; q.b = p.b; q.out = p.out;
+        q.a_bytes = (unsigned)((size_t)p.M * p.Cab);
+        q.b_bytes = (unsigned)((size_t)p.N * p.Hi * p.Wi * p.Cbb);
+        q.Ho = p.Ho; q.Wo = p.Wo; q.Hi = p.Hi; q.Wi = p.Wi; q.Cab = p.Cab; q.Cbb = p.Cbb;
+        q.nca = p.CaRows / 64; q.ncb = p.cpc * 8 / 64;
+        q.rows = (int)wr_rows(p); q.rps = rps[i];
+        q.blk0 = blocks; q.nblk = nsplit[i] * q.nca * q.ncb;
+        q.reflect = p.pad_mode == MT_PAD_REFLECT;
+        blocks += (q.nblk + 7) & ~7;
+      }
+      if (m.n == 0) break;
+      if (S == 1) hipLaunchKernelGGL((wgrad_rows_kernel<1>), dim3((unsigned)blocks), dim3(576), 0, s, m);
+      else hipLaunchKernelGGL((wgrad_rows_kernel<2>), dim3((unsigned)blocks), dim3(576), 0, s, m);
+      MT_LAUNCH_CHECK();
+      g_wr_launches++;
+    }
+  }
   return 0;
+}
+
+int mt_launch_wgrad_rows(const WgradParams& p, int nsplit, hipStream_t s) {
+  MT_CHECK(p.rows_rs > 0, "wgrad_rows: no split");
+  const int rps = p.rows_rs;
+  return mt_launch_wgrad_rows_multi(1, &p, &nsplit, &rps, s);
 }

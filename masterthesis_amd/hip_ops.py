@@ -706,7 +706,8 @@ class _Conv(torch.autograd.Function):
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
-            if gw is not None and not need_b and (_wgrad_group_defer(ctx, desc, x, dy, gw)
+            if gw is not None and not need_b and (_wgrad_rows_defer(ctx, desc, x, dy, gw)
+                                                  or _wgrad_group_defer(ctx, desc, x, dy, gw)
                                                   or _wgrad_share_defer(ctx, desc, x, dy, gw)
                                                   or _wgrad_finish_defer(ctx, desc, x, dy, gw)):
                 return dx, None, db, None          # launched with its group (or at the end of this backward pass)
@@ -894,6 +895,62 @@ def _wgrad_finish_defer(ctx, desc, x, dy, gw):
     return True
 
 
+# Shared launches of the row walker (round 4; csrc/wgrad_rows_kernel.hip).  The 3x3 layers of the encoders and the decoder at 64-256
+# channels each fill the chip only by cutting their pixel reduction ~256 ways (38 MB of slabs per layer); parked until the end of
+# the backward pass, all of them go out in ONE launch per stride class (mt_conv_bwd_weight_rows_multi) with a share of the compute
+# units each, and one batched slab sum.  Not with a live gradient-ready hook (a data-parallel bucket wants its gradients early).
+# MT_WGRAD_ROWS_MULTI=0 / set_wgrad_rows_multi(False): every such layer launches where autograd reaches it.
+_WGRAD_ROWS_ON = [os.environ.get("MT_WGRAD_ROWS_MULTI", "1") != "0"]
+_WGRAD_ROWS_MAX = 48
+
+
+def set_wgrad_rows_multi(on):
+    flush_wgrad_groups()
+    _WGRAD_ROWS_ON[0] = bool(on)
+
+
+def _wgrad_rows_defer(ctx, desc, x, dy, gw):
+    if not _WGRAD_ROWS_ON[0] or not _WGRAD_GROUP_ON[0] or getattr(ctx.owner, "_mt_ready_hook", None) is not None:
+        return False
+    lib = L.load()
+    rkey = ("rows_ok", _desc_key(desc), lib.mt_kernel_variant_epoch())
+    ok = _WGRAD_QUEUE["gmax"].get(rkey)
+    if ok is None:
+        ok = bool(lib.mt_conv_bwd_weight_rows_ok(C.byref(desc)))
+        _WGRAD_QUEUE["gmax"][rkey] = ok
+    if not ok or not _wgrad_arm():
+        return False
+    q = _WGRAD_QUEUE["pending"].setdefault(("rows",), [])
+    q.append((ctx, desc, x, dy, gw, _park_event()))
+    if len(q) >= _WGRAD_ROWS_MAX:
+        _wgrad_rows_launch(_WGRAD_QUEUE["pending"].pop(("rows",)))
+    return True
+
+
+def _wgrad_rows_launch(items):
+    """every parked row-walker problem in one library call; uses of one weight next to each other (one slab sum per weight)"""
+    _wait_parked(items)
+    order = {}
+    for it in items:
+        order.setdefault(it[4].data_ptr(), len(order))
+    items = sorted(items, key=lambda it: order[it[4].data_ptr()])          # (stable: first-use order of the weights)
+    lib = L.load()
+    n = len(items)
+    descs = (L.ConvDesc * n)(*[it[1] for it in items])
+    nws = int(lib.mt_conv_bwd_weight_rows_multi_ws_bytes(n, descs))
+    if nws == 0:
+        raise RuntimeError("mt_conv_bwd_weight_rows_multi_ws_bytes: " + (lib.mt_last_error() or b"").decode())
+    ws = torch.empty((nws,), dtype=torch.uint8, device=items[0][2].device)
+    xs = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    dys = (C.c_void_p * n)(*[it[3].data_ptr() for it in items])
+    gws = (C.c_void_p * n)(*[it[4].data_ptr() for it in items])
+    with _oplog("wgrad_rows", items[0][1], (0, n)):
+        L.check(lib.mt_conv_bwd_weight_rows_multi(n, descs, xs, dys, gws, _ptr(ws), nws, 1, _stream()),
+                "mt_conv_bwd_weight_rows_multi")
+    for it in items:
+        _grad_use_done(it[0])
+
+
 def _wgrad_finish_launch(items):
     """the slab sums of every parked (desc, slabs, param.grad) in as few launches as the library needs"""
     cur = torch.cuda.current_stream()
@@ -948,6 +1005,8 @@ def flush_wgrad_groups():
     for key, items in pend.items():
         if key == ("finish",):                       # slab sums waiting for the end of the pass
             _wgrad_finish_launch(items)
+        elif key == ("rows",):                       # 3x3 layers that share launches of the row walker
+            _wgrad_rows_launch(items)
         elif isinstance(key, tuple):                 # ("owner", id): uses of one weight
             _wgrad_shared_launch(items)
         else:

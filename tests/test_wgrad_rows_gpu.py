@@ -97,3 +97,61 @@ def test_row_walker_declines_what_it_cannot_walk(hip_device):
         ops.conv2d(x, w, None, stride=s, pad=p).sum().backward()
         assert lib.mt_kernel_variant_launches(5) == n0
         assert torch.isfinite(w.grad).all()
+
+
+def _net_grads(ops, dev, seed, N):
+    """an encoder / decoder shaped chain of eligible layers, one of them applied to two inputs (two uses of one weight)"""
+    g = torch.Generator().manual_seed(seed)
+
+    def w_(*shape):
+        fan = shape[1] * 9
+        w = (torch.randn(*shape, generator=g) * fan ** -0.5).bfloat16().float().to(dev).requires_grad_()
+        w.grad = torch.zeros_like(w)               # (accumulated into in place, as the optimizer's flat gradient buffers are)
+        return w
+    ws = {"down1": w_(128, 64, 3, 3), "same": w_(128, 128, 3, 3), "down2": w_(256, 128, 3, 3), "up1": w_(256, 128, 3, 3),
+          "up2": w_(128, 64, 3, 3), "s64": w_(64, 64, 3, 3)}
+    xa = torch.randn(N, 64, 128, 128, generator=g).bfloat16().float().to(dev)
+    xb = torch.randn(N, 64, 128, 128, generator=g).bfloat16().float().to(dev)
+
+    def enc(x):
+        h = ops.conv2d(x, ws["s64"], None, stride=1, pad=1, pad_mode="reflect", act="relu")
+        h = ops.conv2d(h, ws["down1"], None, stride=2, pad=1, pad_mode="reflect", act="relu")
+        h = ops.conv2d(h, ws["same"], None, stride=1, pad=1, pad_mode="zero", act="lrelu")
+        return ops.conv2d(h, ws["down2"], None, stride=2, pad=1, pad_mode="reflect")
+    ha, hb = enc(xa), enc(xb)                      # every encoder weight is used twice in this backward pass
+    h = ops.conv_transpose2d(ha + hb, ws["up1"], None, stride=2, pad=1, out_pad=1, act="relu")
+    y = ops.conv_transpose2d(h, ws["up2"], None, stride=2, pad=1, out_pad=1)
+    t = torch.randn(*y.shape, generator=g).to(dev)
+    (y.float() * t).sum().backward()
+    torch.cuda.synchronize()
+    return {k: v.grad.detach().float().cpu() for k, v in ws.items()}
+
+
+def test_row_walker_shared_launches_match_per_layer_tile_kernels(hip_device):
+    """ten weight-gradient problems of one backward pass (six weights, four of them used twice) parked and handed over at once:
+    two launches of the row walker (stride 1 / stride 2 class) and one batched slab sum -- against the same pass with every
+    weight gradient on the tile kernels where autograd reaches it"""
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = L.load()
+    prev = lib.mt_kernel_variant_enable(5, 1)
+    fused_before = ops._FUSE_WGRAD_ACC[0]
+    try:
+        ops.set_fused_grad_accumulation(True)          # (what the models' FusedAdam switches on: gradients added into param.grad)
+        ops.set_wgrad_rows_multi(True)
+        n0 = lib.mt_kernel_variant_launches(5)
+        g1 = _net_grads(ops, hip_device, 20261005, 4)
+        used = lib.mt_kernel_variant_launches(5) - n0
+        assert used == 2, f"launches of the row walker for the whole pass: {used}"
+        ops.set_wgrad_rows_multi(False)
+        lib.mt_kernel_variant_enable(5, 0)
+        n0 = lib.mt_kernel_variant_launches(5)
+        g0 = _net_grads(ops, hip_device, 20261005, 4)
+        assert lib.mt_kernel_variant_launches(5) == n0
+    finally:
+        ops.set_wgrad_rows_multi(True)
+        ops.set_fused_grad_accumulation(fused_before)
+        lib.mt_kernel_variant_enable(5, prev)
+    for k in g0:
+        rel = ((g1[k] - g0[k]).norm() / g0[k].norm()).item()
+        assert rel < 2e-5, f"{k}: rel L2 {rel:.3e} between the shared launches and the per-layer tile kernels"
