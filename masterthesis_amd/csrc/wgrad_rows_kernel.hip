@@ -13,11 +13,13 @@
 //     tick brings in ONE new row segment of dY (32 pixels) and `is` new row segments of x (32 is + 2 pixels, halo included) by LDS-DMA;
 //     the three input rows a tick needs sit in a ring of row segments, so every input byte reaches LDS once per workgroup instead of
 //     nine times, and the tap shift is an LDS address.
-//   * LDS LAYOUT FOR THE TRANSPOSING READS: a segment is stored as one 32-byte-per-pixel PLANE per 16-channel MFMA fragment
-//     (stride 2: per fragment an even and an odd pixel plane, so that the 32 gathered pixels of a k-step are consecutive plane
-//     entries for every tap), entry index XOR-ed with ((e >> 3) & 1) << 2 on the source side of the lane-linear LDS-DMA: the eight
-//     rows a 32-lane group of ds_read_b64_tr_b16 touches -- entries e0 .. e0 + 3 and e0 + 8 .. e0 + 11 for ANY e0 -- then cover the 64
-//     banks exactly once (no conflicts at any tap shift).
+//   * LDS LAYOUT FOR THE TRANSPOSING READS: a segment is stored pixel-major, 128 bytes (the block's 64 channels) per entry (stride
+//     2: an even and an odd pixel plane, so that the 32 gathered pixels of a k-step are consecutive entries for every tap), the
+//     32-byte slot of a 16-channel MFMA fragment XOR-ed with key(e) = bit 1 | bit 3 << 1 of the entry index on the source side of
+//     the lane-linear LDS-DMA: the eight rows a 32-lane group of ds_read_b64_tr_b16 touches -- entries e0 .. e0 + 3 and e0 + 8 ..
+//     e0 + 11 for ANY e0 -- then cover the 64 banks exactly once (no conflicts at any tap shift), and a copy instruction fetches
+//     eight WHOLE 128-byte pixel rows (a first layout with one 32-byte-per-pixel plane per fragment read 32 quarter rows per
+//     instruction and ran at the texture addresser's pace).
 //   * ONE BARRIER PER TICK; the copies of the next WR_D ticks are in flight behind a counted vmcnt.
 // Each (split, a-block, c-block) workgroup writes its part of the split's fp32 slab [CaRows][taps][Cb] -- the same slab layout as
 // wgrad_kernel / wgrad_pipe_kernel, summed by the same unpack kernels.  Chosen by wgrad_split (conv_api.hip) through
@@ -28,12 +30,11 @@
 
 constexpr int WR_D = 4;                     // ticks of copies in flight
 constexpr int WR_NA = WR_D + 1;             // ring slots of the dense operand (4 KiB each)
-constexpr int WR_APLANE = 1024;             // 32 entries x 32 B
-constexpr int WR_ASLOT = 4 * WR_APLANE;
-constexpr int WR_BPLANE = 1280;             // 40 entries x 32 B (34 / 33 used)
+constexpr int WR_ASLOT = 4096;              // 32 entries x 128 B
+constexpr int WR_BPLANE = 5120;             // 40 entries x 128 B (34 / 33 used)
 template <int S> struct WrGeom {
   static constexpr int NB = S * WR_D + 3;                     // ring slots of gathered row segments
-  static constexpr int BSLOT = (S == 1 ? 4 : 8) * WR_BPLANE;  // bytes of one row segment: [parity][fragment][entry][32 B]
+  static constexpr int BSLOT = S * WR_BPLANE;                 // bytes of one row segment: [parity][entry][128 B]
   static constexpr int CB = BSLOT / 1024;                     // copies per row segment (5 / 10)
   static constexpr int NCOPY = 4 + S * CB;                    // copies per tick (9 / 24)
   static constexpr int CPW = (NCOPY + 8) / 9;                 // ... per wave (1 / 3; the spare ones are dummies)
@@ -69,7 +70,9 @@ __device__ __forceinline__ s16x4 wr_tr16(unsigned addr) {     // (inline asm: se
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
   return r;
 }
-__device__ __forceinline__ int wr_swz(int e) { return e ^ (((e >> 3) & 1) << 2); }
+__device__ __forceinline__ int wr_key(int e) { return ((e >> 1) & 1) | (((e >> 3) & 1) << 1); }
+// byte offset of fragment f's 32-byte slot of entry e
+__device__ __forceinline__ unsigned wr_slot(int e, int f) { return (unsigned)(e * 128 + ((f ^ wr_key(e)) << 5)); }
 
 template <int S>
 __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
@@ -114,15 +117,17 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   // ---- fragment addresses: lane (g, qq, pp) supplies [entry 8 g + qq (+ 4)][channels 4 pp .. 4 pp + 3] of a fragment plane ----
   const int fgq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const int kk = 8 * fgq + qq;
-  const unsigned aoff0 = (unsigned)(wr_swz(kk) * 32 + pp * 8), aoff1 = (unsigned)(wr_swz(kk + 4) * 32 + pp * 8);
-  unsigned boff0, boff1;
-  if constexpr (S == 1) {
-    boff0 = (unsigned)(wr_swz(kk + dwo) * 32 + pp * 8);
-    boff1 = (unsigned)(wr_swz(kk + dwo + 4) * 32 + pp * 8);
-  } else {
-    const int par = dwo & 1, hx = kk + (dwo >> 1);
-    boff0 = (unsigned)(par * 4 * WR_BPLANE + wr_swz(hx) * 32 + pp * 8);
-    boff1 = (unsigned)(par * 4 * WR_BPLANE + wr_swz(hx + 4) * 32 + pp * 8);
+  unsigned aoff[2][4], boff[2][4];
+  {
+    const int par = S == 2 ? (dwo & 1) : 0;
+    const int eb = S == 2 ? kk + (dwo >> 1) : kk + dwo;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        aoff[h][f] = wr_slot(kk + 4 * h, f) + (unsigned)(pp * 8);
+        boff[h][f] = (unsigned)(par * WR_BPLANE) + wr_slot(eb + 4 * h, f) + (unsigned)(pp * 8);
+      }
   }
 
   f32x4 acc[4][4];
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
 #pragma unroll
   for (int e = 0; e < G::CPW; e++) {
     const int q = wv + 9 * e;
-    if (q < 4) { ckind[e] = 0; crow[e] = 0; cdst[e] = (unsigned)q * WR_APLANE; }
+    if (q < 4) { ckind[e] = 0; crow[e] = 0; cdst[e] = (unsigned)q * 1024u; }
     else if (q < G::NCOPY) { const int qb = q - 4; ckind[e] = 1; crow[e] = qb / G::CB; cdst[e] = (unsigned)(qb - crow[e] * G::CB) * 1024u; }
     else { ckind[e] = 2; crow[e] = 0; cdst[e] = 0; }
   }
@@ -155,16 +160,14 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
 #pragma unroll
     for (int e = 0; e < G::CPW; e++) {
       const int q = wv + 9 * e;
+      const int sub = lane >> 3, slot = (lane & 7) >> 1, half = lane & 1;     // a copy = 8 entries x 128 B
       if (q < 4) {
-        const int pos = lane >> 1, half = lane & 1, k = wr_swz(pos);
-        loff[e] = (unsigned)k * cab_b + (unsigned)cab * 128u + (unsigned)q * 32u + (unsigned)half * 16u;
+        const int k = 8 * q + sub, f = slot ^ wr_key(k);
+        loff[e] = (unsigned)k * cab_b + (unsigned)cab * 128u + (unsigned)f * 32u + (unsigned)half * 16u;
       } else if (q < G::NCOPY) {
         const int qb = q - 4, i = qb - (qb / G::CB) * G::CB;
-        const int o = i * 1024 + lane * 16;
-        const int par = S == 2 ? o / (4 * WR_BPLANE) : 0;
-        const int f = (o - par * 4 * WR_BPLANE) / WR_BPLANE;
-        const int rem = o - par * 4 * WR_BPLANE - f * WR_BPLANE;
-        const int hx = wr_swz(rem >> 5), half = (rem >> 4) & 1;
+        const int par = S == 2 ? i / 5 : 0;
+        const int hx = 8 * (i - par * 5) + sub, f = slot ^ wr_key(hx);
         const int c = S == 2 ? 2 * hx + par : hx;                  // segment-relative input pixel (0 = the left halo pixel)
         bool ok = c < (S == 2 ? 65 : 34);
         int wi = S * w0 - 1 + c;
@@ -231,19 +234,16 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
         const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
         const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
         bf16x8 af[4], bf[4];
-#define WR_FRAG(dst, base, o0, o1, OFF)                                                                     \
+#define WR_FRAG(dst, base, o0, o1)                                                                          \
         {                                                                                                   \
-          const s16x4 lo = wr_tr16<OFF>(base + o0), hi = wr_tr16<OFF>(base + o1);                           \
+          const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                               \
           dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));        \
         }
-        WR_FRAG(af[0], sa, aoff0, aoff1, 0 * WR_APLANE);
-        WR_FRAG(af[1], sa, aoff0, aoff1, 1 * WR_APLANE);
-        WR_FRAG(af[2], sa, aoff0, aoff1, 2 * WR_APLANE);
-        WR_FRAG(af[3], sa, aoff0, aoff1, 3 * WR_APLANE);
-        WR_FRAG(bf[0], sb, boff0, boff1, 0 * WR_BPLANE);
-        WR_FRAG(bf[1], sb, boff0, boff1, 1 * WR_BPLANE);
-        WR_FRAG(bf[2], sb, boff0, boff1, 2 * WR_BPLANE);
-        WR_FRAG(bf[3], sb, boff0, boff1, 3 * WR_BPLANE);
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+          WR_FRAG(af[f], sa, aoff[0][f], aoff[1][f]);
+          WR_FRAG(bf[f], sb, boff[0][f], boff[1][f]);
+        }
 #undef WR_FRAG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
