@@ -28,21 +28,26 @@
 #include <stdlib.h>
 #include <string.h>
 
-constexpr int WR_D = 4;                     // ticks of copies in flight
-constexpr int WR_NA = WR_D + 1;             // ring slots of the dense operand (4 KiB each)
 constexpr int WR_ASLOT = 4096;              // 32 entries x 128 B
 constexpr int WR_BPLANE = 5120;             // 40 entries x 128 B (34 / 33 used)
 template <int S> struct WrGeom {
-  static constexpr int NB = S * WR_D + 3;                     // ring slots of gathered row segments
+#ifndef MT_WR_D1
+#define MT_WR_D1 8
+#endif
+#ifndef MT_WR_D2
+#define MT_WR_D2 5
+#endif
+  static constexpr int D = S == 1 ? MT_WR_D1 : MT_WR_D2;      // ticks of copies in flight (what the latency of the copies needs, what LDS holds)
+  static constexpr int NA = D + 1;                            // ring slots of the dense operand (4 KiB each)
+  static constexpr int NB = S * D + 3;                     // ring slots of gathered row segments
   static constexpr int BSLOT = S * WR_BPLANE;                 // bytes of one row segment: [parity][entry][128 B]
   static constexpr int CB = BSLOT / 1024;                     // copies per row segment (5 / 10)
   static constexpr int NCOPY = 4 + S * CB;                    // copies per tick (9 / 24)
-  static constexpr int CPW = (NCOPY + 8) / 9;                 // ... per wave (1 / 3; the spare ones are dummies)
+  static constexpr int CPW = (NCOPY + 7) / 8;                 // ... per wave at most (stride 1: wave 0 has two, the others one; stride 2: three)
   static constexpr int WARM = S == 1 ? 2 : 1;                 // load-only ticks at the top of a strip
   static constexpr int A_OFF = 0;
-  static constexpr int B_OFF = WR_NA * WR_ASLOT;
-  static constexpr int DUMMY_OFF = B_OFF + NB * BSLOT;
-  static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+  static constexpr int B_OFF = NA * WR_ASLOT;
+  static constexpr int LDS_BYTES = B_OFF + NB * BSLOT;
 };
 
 // one weight-gradient problem of a launch (several layers' problems share a launch: mt_launch_wgrad_rows_multi)
@@ -75,7 +80,7 @@ __device__ __forceinline__ int wr_key(int e) { return ((e >> 1) & 1) | (((e >> 3
 __device__ __forceinline__ unsigned wr_slot(int e, int f) { return (unsigned)(e * 128 + ((f ^ wr_key(e)) << 5)); }
 
 template <int S>
-__global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
+__global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
   using G = WrGeom<S>;
   constexpr unsigned OOB = 0x80000000u;
   static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -86,8 +91,9 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   const unsigned lds_base = (unsigned)(size_t)(lds_char_ptr)lds0;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = filter tap
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = filter tap 0 .. 7 (+ two of the sixteen tiles of tap 8)
   const int dh = wv / 3 - 1, dwo = wv % 3;                         // tap row offset, tap column offset + 1
+  const int a9 = wv >> 1, fb9 = 2 * (wv & 1);                      // tap 8 (dh = 1, dwo = 2): a-fragment a9 x c-fragments fb9, fb9 + 1
 
   // ---- which problem of the launch (blocks of a problem are consecutive, blk0 a multiple of 8), which block of its dW, which
   // range of its k-steps (k-step = (strip, output row), strip-major) ----
@@ -117,17 +123,22 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   // ---- fragment addresses: lane (g, qq, pp) supplies [entry 8 g + qq (+ 4)][channels 4 pp .. 4 pp + 3] of a fragment plane ----
   const int fgq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const int kk = 8 * fgq + qq;
-  unsigned aoff[2][4], boff[2][4];
+  unsigned aoff[2][4], boff[2][4], aoff9[2], boff9[2][2];
   {
     const int par = S == 2 ? (dwo & 1) : 0;
     const int eb = S == 2 ? kk + (dwo >> 1) : kk + dwo;
+    const int eb9 = S == 2 ? kk + 1 : kk + 2;                      // (tap 8: column offset + 1 = 2 -> even plane, entry + 1)
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < 2; h++) {
 #pragma unroll
       for (int f = 0; f < 4; f++) {
         aoff[h][f] = wr_slot(kk + 4 * h, f) + (unsigned)(pp * 8);
         boff[h][f] = (unsigned)(par * WR_BPLANE) + wr_slot(eb + 4 * h, f) + (unsigned)(pp * 8);
       }
+      aoff9[h] = wr_slot(kk + 4 * h, a9) + (unsigned)(pp * 8);
+      boff9[h][0] = wr_slot(eb9 + 4 * h, fb9) + (unsigned)(pp * 8);
+      boff9[h][1] = wr_slot(eb9 + 4 * h, fb9 + 1) + (unsigned)(pp * 8);
+    }
   }
 
   f32x4 acc[4][4];
@@ -135,18 +146,20 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc9[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
-  // copy duties of this wave: copy q = wv + 9 e of a tick's NCOPY (q < 4: plane q of the dense segment; else row (q-4) / CB,
-  // KiB (q-4) % CB of a gathered row segment; q >= NCOPY: dummy): kind / row / destination are wave-uniform
+  // copy duties of this wave: copy q = wv + 8 e of a tick's NCOPY (q < 4: KiB q of the dense segment; else row (q-4) / CB,
+  // KiB (q-4) % CB of a gathered row segment; q >= NCOPY: none): kind / row / destination are wave-uniform
   int ckind[G::CPW], crow[G::CPW];
   unsigned cdst[G::CPW];
 #pragma unroll
   for (int e = 0; e < G::CPW; e++) {
-    const int q = wv + 9 * e;
+    const int q = wv + 8 * e;
     if (q < 4) { ckind[e] = 0; crow[e] = 0; cdst[e] = (unsigned)q * 1024u; }
     else if (q < G::NCOPY) { const int qb = q - 4; ckind[e] = 1; crow[e] = qb / G::CB; cdst[e] = (unsigned)(qb - crow[e] * G::CB) * 1024u; }
     else { ckind[e] = 2; crow[e] = 0; cdst[e] = 0; }
   }
+  const bool two_copies = G::NCOPY - 8 * (G::CPW - 1) > wv;        // this wave issues CPW copies per tick (else CPW - 1)
 
   for (int gpos = gbeg; gpos < gend;) {
     // ---- one run of consecutive output rows h0 .. h1 - 1 of one 32-pixel column strip ----
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
     unsigned loff[G::CPW];          // per-lane source offset inside the row (bytes), or OOB
 #pragma unroll
     for (int e = 0; e < G::CPW; e++) {
-      const int q = wv + 9 * e;
+      const int q = wv + 8 * e;
       const int sub = lane >> 3, slot = (lane & 7) >> 1, half = lane & 1;     // a copy = 8 entries x 128 B
       if (q < 4) {
         const int k = 8 * q + sub, f = slot ^ wr_key(k);
@@ -191,7 +204,11 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
           const int h = h0 + l_tick - G::WARM;
           const bool ok = live && l_tick >= G::WARM;               // (h < h1 follows from l_tick < T)
           const unsigned base = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
+#ifdef MT_WR_EXP_NOCOPY
+          const unsigned vo = OOB | (base & 1u);
+#else
           const unsigned vo = ok ? base + loff[e] : OOB;
+#endif
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::A_OFF + l_aslot * WR_ASLOT + cdst[e]), 16, vo, 0, 0, 0);
         } else if (ckind[e] == 1) {
           int hi = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
@@ -201,39 +218,51 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
           }
           const bool ok = live && (unsigned)hi < (unsigned)Hi;
           const unsigned base = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
+#ifdef MT_WR_EXP_NOCOPY
+          const unsigned vo = OOB | (base & 1u) | (ok ? 2u : 0u);
+#else
           const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
+#endif
           int bs = l_bslot + crow[e];
           bs = bs >= G::NB ? bs - G::NB : bs;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lds0 + G::B_OFF + bs * G::BSLOT + cdst[e]), 16, vo, 0, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::DUMMY_OFF), 16, OOB, 0, 0, 0);
         }
       }
       l_tick++;
-      l_aslot = l_aslot + 1 == WR_NA ? 0 : l_aslot + 1;
+      l_aslot = l_aslot + 1 == G::NA ? 0 : l_aslot + 1;
       l_bslot += S;
       l_bslot = l_bslot >= G::NB ? l_bslot - G::NB : l_bslot;
     };
 
 #pragma unroll
-    for (int s = 0; s < WR_D; s++) issue_tick();
+    for (int s = 0; s < G::D; s++) issue_tick();
 
-    // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)
+    // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)  (tap 8: dh = 1)
     int c_aslot = 0;
     int c_bslot = (S == 1 ? dh - 1 : dh) + G::NB;
     c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+    int c_bslot9 = (S == 1 ? 0 : 1);
 
-    for (int j = 0; j < T; j++) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * G::CPW) : "memory");
+    // Software pipeline over two fragment sets: tick j's fragments are read from LDS while the MFMAs of tick j - 1 run.  Order per
+    // tick: [own copies of tick j landed, own reads of tick j - 1 retired] barrier [copies of tick j + D] [reads of tick j]
+    // [MFMAs of tick j - 1].  The ring slot a tick's copies refill was last read one tick earlier, before the barrier.
+    bf16x8 fP[11], fQ[11];           // 0..3 a-fragments, 4..7 c-fragments of the wave's tap, 8 a-fragment + 9, 10 c-fragments of tap 8
+    auto tick = [&](int j, bf16x8 (&rd)[11], const bf16x8 (&mm)[11]) {
+      if (two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * (G::CPW - 1)) : "memory");
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                  // every wave's copies of tick j have landed; tick j - 1 has been read
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       issue_tick();
       __builtin_amdgcn_sched_barrier(0);
-      if (j >= G::WARM) {
+#ifdef MT_WR_EXP_NOREAD
+      if (j == G::WARM) {
+#else
+      if (j >= G::WARM && j < T) {
+#endif
         const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
         const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
-        bf16x8 af[4], bf[4];
+        const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
 #define WR_FRAG(dst, base, o0, o1)                                                                          \
         {                                                                                                   \
           const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                               \
@@ -241,24 +270,41 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
         }
 #pragma unroll
         for (int f = 0; f < 4; f++) {
-          WR_FRAG(af[f], sa, aoff[0][f], aoff[1][f]);
-          WR_FRAG(bf[f], sb, boff[0][f], boff[1][f]);
+          WR_FRAG(rd[f], sa, aoff[0][f], aoff[1][f]);
+          WR_FRAG(rd[4 + f], sb, boff[0][f], boff[1][f]);
         }
+        WR_FRAG(rd[8], sa, aoff9[0], aoff9[1]);
+        WR_FRAG(rd[9], sb9, boff9[0][0], boff9[1][0]);
+        WR_FRAG(rd[10], sb9, boff9[0][1], boff9[1][1]);
 #undef WR_FRAG
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef MT_WR_EXP_NOMFMA
+      if (j == G::WARM + 1) {
+#else
+      if (j > G::WARM && j <= T) {
+#endif
         // gathered operand as MFMA A: a lane ends with 4 consecutive columns of one a-channel (16-byte slab stores)
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
           for (int b = 0; b < 4; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[4 + b], mm[a], acc[a][b], 0, 0, 0);
+        acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[9], mm[8], acc9[0], 0, 0, 0);
+        acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[10], mm[8], acc9[1], 0, 0, 0);
       }
-      c_aslot = c_aslot + 1 == WR_NA ? 0 : c_aslot + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      c_aslot = c_aslot + 1 == G::NA ? 0 : c_aslot + 1;
       c_bslot += S;
       c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+      c_bslot9 += S;
+      c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
+    };
+    for (int j = 0; j <= T; j += 2) {
+      tick(j, fP, fQ);
+      tick(j + 1, fQ, fP);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // the trailing (all-zero) copies must have landed, and every wave must be done with the ring, before the next run refills it
     // (or the wave exits)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -268,6 +314,9 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
   }
 
   // ---- epilogue: this workgroup's 64 x 9 x 64 block of the split's fp32 slab [CaRows][taps][Cb] ----
+#ifdef MT_WR_EXP_NOSLAB
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   const int fr = lane & 15, fg = lane >> 4;
   const int cbt = ncb * 64, ncols = 9 * cbt;
   float* const slab = pout + (size_t)split * (size_t)(nca * 64) * ncols;
@@ -279,6 +328,12 @@ __global__ __launch_bounds__(576) void wgrad_rows_kernel(const WrMulti m) {
       const int col = wv * cbt + cbb * 64 + b * 16 + fg * 4;
       *reinterpret_cast<f32x4*>(slab + (size_t)ca * ncols + col) = acc[a][b];
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int ca = cab * 64 + a9 * 16 + fr;
+    const int col = 8 * cbt + cbb * 64 + (fb9 + i) * 16 + fg * 4;
+    *reinterpret_cast<f32x4*>(slab + (size_t)ca * ncols + col) = acc9[i];
   }
 }
 
@@ -382,8 +437,8 @@ int mt_launch_wgrad_rows_multi(int n, const WgradParams* ps, const int* nsplit, 
         blocks += (q.nblk + 7) & ~7;
       }
       if (m.n == 0) break;
-      if (S == 1) hipLaunchKernelGGL((wgrad_rows_kernel<1>), dim3((unsigned)blocks), dim3(576), 0, s, m);
-      else hipLaunchKernelGGL((wgrad_rows_kernel<2>), dim3((unsigned)blocks), dim3(576), 0, s, m);
+      if (S == 1) hipLaunchKernelGGL((wgrad_rows_kernel<1>), dim3((unsigned)blocks), dim3(512), 0, s, m);
+      else hipLaunchKernelGGL((wgrad_rows_kernel<2>), dim3((unsigned)blocks), dim3(512), 0, s, m);
       MT_LAUNCH_CHECK();
       g_wr_launches++;
     }

@@ -706,6 +706,16 @@ class _Conv(torch.autograd.Function):
 
             gw = _fused_grad_target(ctx.owner) if ctx.needs_input_grad[1] else None
             gbw = gb if need_b else None
+            if need_b and gw is not None and gbw is not None and _wgrad_rows_parkable(ctx, desc):
+                # a layer of the row walker's shared launches whose bias gradient rides on the weight-gradient call (no fused
+                # activation in front of it, e.g. ConvTranspose2d -> LayerNorm): the bias gradient now, by itself (the column
+                # sums of dy: the same launch mt_conv_bwd_weight would make first), the weight gradient with the others
+                nws = _desc_info(lib, desc)[5]
+                ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+                ns = C.c_int(0)
+                L.check(lib.mt_conv_bwd_weight_partial(C.byref(desc), _ptr(x), _ptr(dy), _ptr(gbw), _ptr(ws), nws, 1, 0, C.byref(ns),
+                                                       _stream()), "mt_conv_bwd_weight_partial")
+                need_b, gbw = False, None
             if gw is not None and not need_b and (_wgrad_rows_defer(ctx, desc, x, dy, gw)
                                                   or _wgrad_group_defer(ctx, desc, x, dy, gw)
                                                   or _wgrad_share_defer(ctx, desc, x, dy, gw)
@@ -909,7 +919,8 @@ def set_wgrad_rows_multi(on):
     _WGRAD_ROWS_ON[0] = bool(on)
 
 
-def _wgrad_rows_defer(ctx, desc, x, dy, gw):
+def _wgrad_rows_parkable(ctx, desc):
+    """would _wgrad_rows_defer park this weight gradient?"""
     if not _WGRAD_ROWS_ON[0] or not _WGRAD_GROUP_ON[0] or getattr(ctx.owner, "_mt_ready_hook", None) is not None:
         return False
     lib = L.load()
@@ -918,7 +929,11 @@ def _wgrad_rows_defer(ctx, desc, x, dy, gw):
     if ok is None:
         ok = bool(lib.mt_conv_bwd_weight_rows_ok(C.byref(desc)))
         _WGRAD_QUEUE["gmax"][rkey] = ok
-    if not ok or not _wgrad_arm():
+    return bool(ok and _wgrad_arm())
+
+
+def _wgrad_rows_defer(ctx, desc, x, dy, gw):
+    if not _wgrad_rows_parkable(ctx, desc):
         return False
     q = _WGRAD_QUEUE["pending"].setdefault(("rows",), [])
     q.append((ctx, desc, x, dy, gw, _park_event()))

@@ -110,6 +110,9 @@ def _net_grads(ops, dev, seed, N):
         return w
     ws = {"down1": w_(128, 64, 3, 3), "same": w_(128, 128, 3, 3), "down2": w_(256, 128, 3, 3), "up1": w_(256, 128, 3, 3),
           "up2": w_(128, 64, 3, 3), "s64": w_(64, 64, 3, 3)}
+    # a bias whose gradient rides on the weight-gradient call (no fused activation behind the transposed convolution)
+    ws["up2_bias"] = (torch.randn(64, generator=g) * 0.1).to(dev).requires_grad_()
+    ws["up2_bias"].grad = torch.zeros_like(ws["up2_bias"])
     xa = torch.randn(N, 64, 128, 128, generator=g).bfloat16().float().to(dev)
     xb = torch.randn(N, 64, 128, 128, generator=g).bfloat16().float().to(dev)
 
@@ -120,7 +123,7 @@ def _net_grads(ops, dev, seed, N):
         return ops.conv2d(h, ws["down2"], None, stride=2, pad=1, pad_mode="reflect")
     ha, hb = enc(xa), enc(xb)                      # every encoder weight is used twice in this backward pass
     h = ops.conv_transpose2d(ha + hb, ws["up1"], None, stride=2, pad=1, out_pad=1, act="relu")
-    y = ops.conv_transpose2d(h, ws["up2"], None, stride=2, pad=1, out_pad=1)
+    y = ops.conv_transpose2d(h, ws["up2"], ws["up2_bias"], stride=2, pad=1, out_pad=1)
     t = torch.randn(*y.shape, generator=g).to(dev)
     (y.float() * t).sum().backward()
     torch.cuda.synchronize()
@@ -155,3 +158,4 @@ def test_row_walker_shared_launches_match_per_layer_tile_kernels(hip_device):
     for k in g0:
         rel = ((g1[k] - g0[k]).norm() / g0[k].norm()).item()
         assert rel < 2e-5, f"{k}: rel L2 {rel:.3e} between the shared launches and the per-layer tile kernels"
+    assert g1["up2_bias"].abs().max() > 0
