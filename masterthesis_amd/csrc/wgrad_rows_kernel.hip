@@ -7,8 +7,10 @@
 // (64..256 x 9 x 64..128 values) and a reduction over 65 k .. 1 M pixels.  The 128 x 128 tile kernel (wgrad_kernel) ran them at
 // 0.12-0.30 of the matrix peak: every k-step stages a pixel tile of dY and one TAP's gathered tile of x through LDS -- nine copies
 // of every input pixel -- and meets at two barriers per 64 pixels.  Here the output is what stays put:
-//   * A WORKGROUP OWNS A 64 x 9 x 64 BLOCK OF dW IN REGISTERS: nine waves, one per filter tap, each with the 64 x 64 fp32
-//     accumulator of its tap (64 VGPRs).  Channel counts above 64 are further workgroups (blockIdx -> (pixel split, a-block, c-block)).
+//   * A WORKGROUP OWNS A 64 x 9 x 64 BLOCK OF dW IN REGISTERS: eight waves, wave t with the 64 x 64 fp32 accumulator of filter tap
+//     t (64 VGPRs) plus two of the sixteen 16 x 16 tiles of tap 8 (18 MFMAs per wave and k-step: two waves per SIMD, all four SIMDs
+//     level; a first form with nine waves had three on one SIMD).  Channel counts above 64 are further workgroups
+//     (blockIdx -> (problem, pixel split, a-block, c-block)).
 //   * THE REDUCTION WALKS DOWN A 32-PIXEL-WIDE COLUMN STRIP of one image, one output row (= one 32-deep MFMA k-step) per tick.  A
 //     tick brings in ONE new row segment of dY (32 pixels) and `is` new row segments of x (32 is + 2 pixels, halo included) by LDS-DMA;
 //     the three input rows a tick needs sit in a ring of row segments, so every input byte reaches LDS once per workgroup instead of
@@ -20,13 +22,26 @@
 //     e0 + 11 for ANY e0 -- then cover the 64 banks exactly once (no conflicts at any tap shift), and a copy instruction fetches
 //     eight WHOLE 128-byte pixel rows (a first layout with one 32-byte-per-pixel plane per fragment read 32 quarter rows per
 //     instruction and ran at the texture addresser's pace).
-//   * ONE BARRIER PER TICK; the copies of the next WR_D ticks are in flight behind a counted vmcnt.
+//   * ONE BARRIER PER TICK; the copies of the next D ticks (8 at stride 1, 5 at stride 2: what LDS holds) are in flight behind a
+//     counted vmcnt; tick j's fragments are read (two register sets) while the MFMAs of tick j - 1 run; the copy issue is
+//     branch-free.  Nothing in a tick is conditional: a tick without an output row finds zeros in the dense operand's ring slot.
+//   * SEVERAL LAYERS PER LAUNCH: the kernel argument is a table of problems (WrMulti); a workgroup finds its problem from the block
+//     index and walks a run of that problem's k-steps (k-step = (strip, output row), strip-major, runs may cross strips).  A layer
+//     alone fills 256 compute units only by cutting its reduction ~256 ways (38 MB of slabs per layer); the eligible layers of a
+//     whole backward pass share the chip instead (mt_conv_bwd_weight_rows_multi: ~25 slabs per layer for ten layers).
 // Each (split, a-block, c-block) workgroup writes its part of the split's fp32 slab [CaRows][taps][Cb] -- the same slab layout as
-// wgrad_kernel / wgrad_pipe_kernel, summed by the same unpack kernels.  Chosen by wgrad_split (conv_api.hip) through
-// mt_wgrad_rows_plan; MT_WGRAD_ROWS=0 / mt_kernel_variant_enable(5, 0) switch it off.  Parity: tests/test_wgrad_rows_gpu.py.
+// wgrad_kernel / wgrad_pipe_kernel, summed by the same unpack kernels.  Single problems come through wgrad_split (conv_api.hip);
+// MT_WGRAD_ROWS=0 / mt_kernel_variant_enable(5, 0) switch the kernel off.  Parity: tests/test_wgrad_rows_gpu.py.
+// Measured (profiles/round4_wgrad_rows_*): 1.2-1.4x the tile kernel per launch, -0.75 ms of kernel time per --ms_dis step with the
+// shared launches.  Knock-out builds (-DMT_WR_EXP_NOMFMA / NOREAD / NOCOPY / NOSLAB, tools/wgrad_rows_knockouts.sh): a tick costs
+// 0.57 us at stride 1 with everything, 0.39 without the MFMAs, 0.40 without the LDS reads, 0.56 without any memory traffic; LDS is
+// conflict-free (SQ_LDS_BANK_CONFLICT 0) and 38 % busy, the matrix pipes hold 576 of the tick's ~850 cycles: what is left is the
+// lockstep of the two waves of a SIMD around the tick's barrier (both read, then both multiply) -- the ping-pong arrangement of
+// wgrad_pipe_kernel (wave groups half a tick apart) is the next step, not taken this round.
 #include "conv_device.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 constexpr int WR_ASLOT = 4096;              // 32 entries x 128 B
 constexpr int WR_BPLANE = 5120;             // 40 entries x 128 B (34 / 33 used)
@@ -117,8 +132,6 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
   const int gbeg = split * rps;
   const int gend = min(rows, gbeg + rps);                          // (host: gbeg < rows)
 
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, b_bytes, 0x00020000);
 
   // ---- fragment addresses: lane (g, qq, pp) supplies [entry 8 g + qq (+ 4)][channels 4 pp .. 4 pp + 3] of a fragment plane ----
   const int fgq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
@@ -160,6 +173,16 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     else { ckind[e] = 2; crow[e] = 0; cdst[e] = 0; }
   }
   const bool two_copies = G::NCOPY - 8 * (G::CPW - 1) > wv;        // this wave issues CPW copies per tick (else CPW - 1)
+  // (three named resources, not an array: an array of the opaque resource type silently drops the kernel's host-side stub)
+  const __amdgpu_buffer_rsrc_t rsc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(ckind[0] == 0 ? pa : pb), 0, ckind[0] == 0 ? a_bytes : b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(ckind[1] == 0 ? pa : pb), 0, ckind[1] == 0 ? a_bytes : b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(ckind[G::CPW - 1] == 0 ? pa : pb), 0, ckind[G::CPW - 1] == 0 ? a_bytes : b_bytes, 0x00020000);
+  // LDS starts as zeros (a ring slot that no copy has reached yet is read by the unconditional ticks), both fragment sets too
+  for (int i = tid; i < G::LDS_BYTES / 16; i += 512) smem[i] = u32x4{0u, 0u, 0u, 0u};
+  bf16x8 fP[11], fQ[11];           // 0..3 a-fragments, 4..7 c-fragments of the wave's tap, 8 a-fragment + 9, 10 c-fragments of tap 8
+#pragma unroll
+  for (int i = 0; i < 11; i++) { fP[i] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); fQ[i] = fP[i]; }
+  __syncthreads();
 
   for (int gpos = gbeg; gpos < gend;) {
     // ---- one run of consecutive output rows h0 .. h1 - 1 of one 32-pixel column strip ----
@@ -196,46 +219,47 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     }
 
     int l_tick = 0, l_aslot = 0, l_bslot = 0;          // the next tick to load and the ring slots it fills
-    auto issue_tick = [&]() {
+    // one copy of the next tick to load (branch-free: dense / gathered by selects -- the tick's body stays ONE basic block)
+    auto issue_copy = [&](auto ec) {
+      constexpr int e = decltype(ec)::value;
       const bool live = l_tick < T;
-#pragma unroll
-      for (int e = 0; e < G::CPW; e++) {
-        if (ckind[e] == 0) {
-          const int h = h0 + l_tick - G::WARM;
-          const bool ok = live && l_tick >= G::WARM;               // (h < h1 follows from l_tick < T)
-          const unsigned base = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
+      const int h = h0 + l_tick - G::WARM;
+      const bool oka = live && l_tick >= G::WARM;                  // (h < h1 follows from l_tick < T)
+      const unsigned basea = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
+      const int hi0 = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
+      int hr = hi0 < 0 ? -hi0 : hi0;
+      hr = hr >= Hi ? 2 * (Hi - 1) - hr : hr;
+      const int hi = refl ? hr : hi0;
+      const bool okb = live && (unsigned)hi < (unsigned)Hi;
+      const unsigned baseb = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
+      int bs = l_bslot + crow[e];
+      bs = bs >= G::NB ? bs - G::NB : bs;
+      const bool isa = ckind[e] == 0;
+      const bool ok = isa ? oka : okb;
+      const unsigned base = isa ? basea : baseb;
+      const unsigned dst = (isa ? (unsigned)(G::A_OFF + l_aslot * WR_ASLOT) : (unsigned)(G::B_OFF + bs * G::BSLOT)) + cdst[e];
 #ifdef MT_WR_EXP_NOCOPY
-          const unsigned vo = OOB | (base & 1u);
+      const unsigned vo = OOB | (base & 1u) | (ok ? 2u : 0u);
 #else
-          const unsigned vo = ok ? base + loff[e] : OOB;
+      const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
 #endif
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)(lds0 + G::A_OFF + l_aslot * WR_ASLOT + cdst[e]), 16, vo, 0, 0, 0);
-        } else if (ckind[e] == 1) {
-          int hi = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
-          if (refl) {
-            hi = hi < 0 ? -hi : hi;
-            hi = hi >= Hi ? 2 * (Hi - 1) - hi : hi;
-          }
-          const bool ok = live && (unsigned)hi < (unsigned)Hi;
-          const unsigned base = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
-#ifdef MT_WR_EXP_NOCOPY
-          const unsigned vo = OOB | (base & 1u) | (ok ? 2u : 0u);
-#else
-          const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
-#endif
-          int bs = l_bslot + crow[e];
-          bs = bs >= G::NB ? bs - G::NB : bs;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr)(lds0 + G::B_OFF + bs * G::BSLOT + cdst[e]), 16, vo, 0, 0, 0);
-        }
-      }
+      if constexpr (e == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc0, (lds_ptr)(lds0 + dst), 16, vo, 0, 0, 0);
+      else if constexpr (e == 1 && G::CPW > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc1, (lds_ptr)(lds0 + dst), 16, vo, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc2, (lds_ptr)(lds0 + dst), 16, vo, 0, 0, 0);
+    };
+    auto advance_load = [&]() {
       l_tick++;
       l_aslot = l_aslot + 1 == G::NA ? 0 : l_aslot + 1;
       l_bslot += S;
       l_bslot = l_bslot >= G::NB ? l_bslot - G::NB : l_bslot;
     };
-
 #pragma unroll
-    for (int s = 0; s < G::D; s++) issue_tick();
+    for (int s = 0; s < G::D; s++) {
+      issue_copy(std::integral_constant<int, 0>{});
+      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, 1>{});
+      if (two_copies) issue_copy(std::integral_constant<int, G::CPW - 1>{});
+      advance_load();
+    }
 
     // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)  (tap 8: dh = 1)
     int c_aslot = 0;
@@ -243,66 +267,84 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
     int c_bslot9 = (S == 1 ? 0 : 1);
 
-    // Software pipeline over two fragment sets: tick j's fragments are read from LDS while the MFMAs of tick j - 1 run.  Order per
-    // tick: [own copies of tick j landed, own reads of tick j - 1 retired] barrier [copies of tick j + D] [reads of tick j]
-    // [MFMAs of tick j - 1].  The ring slot a tick's copies refill was last read one tick earlier, before the barrier.
-    bf16x8 fP[11], fQ[11];           // 0..3 a-fragments, 4..7 c-fragments of the wave's tap, 8 a-fragment + 9, 10 c-fragments of tap 8
-    auto tick = [&](int j, bf16x8 (&rd)[11], const bf16x8 (&mm)[11]) {
+    // One tick.  Knock-outs (round 4) put the first form of this loop -- barrier, copies, 22 transposing reads, wait, 18 MFMAs, one
+    // after the other -- at 0.21 us of barrier + copy issue, 0.19 us of LDS reads and 0.19 us of MFMAs per tick with NO overlap
+    // between them (a wave can have 15 LDS reads outstanding, so the 16th blocks the issue of everything behind it, and the copy
+    // issue was a chain of wave-uniform branches).  Here tick j's fragments (set rd) are read WHILE the MFMAs of tick j - 1 (set mm)
+    // run, eight reads ahead and then four reads per three MFMAs, and the branch-free copy issue of tick j + D follows in the shadow of
+    // the last MFMAs.  Nothing is conditional: the dense operand's ring slot of a tick without an output row (warm-up, past the end)
+    // holds zeros (out-of-range copies write zeros; LDS is cleared at kernel start), so its MFMAs add 0.
+    auto tick = [&](bf16x8 (&rd)[11], const bf16x8 (&mm)[11]) {
       if (two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * (G::CPW - 1)) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue_tick();
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef MT_WR_EXP_NOREAD
-      if (j == G::WARM) {
-#else
-      if (j >= G::WARM && j < T) {
-#endif
-        const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
-        const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
-        const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
+      const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
+      const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
+      const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
 #define WR_FRAG(dst, base, o0, o1)                                                                          \
-        {                                                                                                   \
-          const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                               \
-          dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));        \
-        }
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-          WR_FRAG(rd[f], sa, aoff[0][f], aoff[1][f]);
-          WR_FRAG(rd[4 + f], sb, boff[0][f], boff[1][f]);
-        }
-        WR_FRAG(rd[8], sa, aoff9[0], aoff9[1]);
-        WR_FRAG(rd[9], sb9, boff9[0][0], boff9[1][0]);
-        WR_FRAG(rd[10], sb9, boff9[0][1], boff9[1][1]);
+      {                                                                                                     \
+        const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                                 \
+        dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));          \
+      }
+#define WR_MMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[4 + b], mm[a], acc[a][b], 0, 0, 0)
+#ifdef MT_WR_EXP_NOREAD
 #undef WR_FRAG
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef MT_WR_EXP_NOMFMA
-      if (j == G::WARM + 1) {
-#else
-      if (j > G::WARM && j <= T) {
+#define WR_FRAG(dst, base, o0, o1) asm volatile("" : "+v"(dst))
 #endif
-        // gathered operand as MFMA A: a lane ends with 4 consecutive columns of one a-channel (16-byte slab stores)
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[4 + b], mm[a], acc[a][b], 0, 0, 0);
-        acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[9], mm[8], acc9[0], 0, 0, 0);
-        acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[10], mm[8], acc9[1], 0, 0, 0);
-      }
+#ifdef MT_WR_EXP_NOMFMA
+#undef WR_MMA
+#define WR_MMA(a, b) asm volatile("" : "+v"(acc[a][b]))
+#endif
+      WR_FRAG(rd[0], sa, aoff[0][0], aoff[1][0]);
+      WR_FRAG(rd[1], sa, aoff[0][1], aoff[1][1]);
+      WR_FRAG(rd[4], sb, boff[0][0], boff[1][0]);
+      WR_FRAG(rd[5], sb, boff[0][1], boff[1][1]);
       __builtin_amdgcn_sched_barrier(0);
+      WR_MMA(0, 0); WR_MMA(0, 1); WR_MMA(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(rd[2], sa, aoff[0][2], aoff[1][2]);
+      WR_FRAG(rd[6], sb, boff[0][2], boff[1][2]);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_MMA(0, 3); WR_MMA(1, 0); WR_MMA(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(rd[3], sa, aoff[0][3], aoff[1][3]);
+      WR_FRAG(rd[7], sb, boff[0][3], boff[1][3]);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_MMA(1, 2); WR_MMA(1, 3); WR_MMA(2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(rd[8], sa, aoff9[0], aoff9[1]);
+      WR_FRAG(rd[9], sb9, boff9[0][0], boff9[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_MMA(2, 1); WR_MMA(2, 2); WR_MMA(2, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(rd[10], sb9, boff9[0][1], boff9[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      WR_MMA(3, 0); WR_MMA(3, 1);
+      // (from here on the scheduler may mix the copies' address arithmetic with the remaining MFMAs)
+      issue_copy(std::integral_constant<int, 0>{});
+      WR_MMA(3, 2); WR_MMA(3, 3);
+      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, 1>{});
+#ifndef MT_WR_EXP_NOMFMA
+      acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[9], mm[8], acc9[0], 0, 0, 0);
+      acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[10], mm[8], acc9[1], 0, 0, 0);
+#endif
+#undef WR_FRAG
+#undef WR_MMA
       c_aslot = c_aslot + 1 == G::NA ? 0 : c_aslot + 1;
       c_bslot += S;
       c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
       c_bslot9 += S;
       c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
+      __builtin_amdgcn_sched_barrier(0);
+      if (two_copies) issue_copy(std::integral_constant<int, G::CPW - 1>{});
+      advance_load();
+      __builtin_amdgcn_sched_barrier(0);
     };
     for (int j = 0; j <= T; j += 2) {
-      tick(j, fP, fQ);
-      tick(j + 1, fQ, fP);
+      tick(fP, fQ);
+      tick(fQ, fP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // the trailing (all-zero) copies must have landed, and every wave must be done with the ring, before the next run refills it
