@@ -870,7 +870,9 @@ extern "C" int mt_conv_bwd_weight_rows_ok(const mt_conv_desc* d) {
   if (mt_stem_wgrad_ok(d) || mt_pointwise_small(d)) return 0;
   WgradParams p;
   wgrad_params(d, nullptr, nullptr, &p);
-  if (mt_wgrad_pipe_ok(d->dtype, p.CaRows, p.cpc, (long)p.M * p.Cab, (long)p.N * p.Hi * p.Wi * p.Cbb)) return 0;   // ping-pong shapes
+  // the 256-multiples keep the ping-pong kernel (each operand byte is read once per 256-wide tile there, four times here) -- except
+  // on small maps, where its splits are too short to pay for their slabs (3x3 256 -> 256 on 32 x 32: 63 us alone, 0.12 of peak)
+  if (mt_wgrad_pipe_ok(d->dtype, p.CaRows, p.cpc, (long)p.M * p.Cab, (long)p.N * p.Hi * p.Wi * p.Cbb) && p.Ho * p.Wo > 1024) return 0;
   return mt_wgrad_rows_ok(d->dtype, p) ? 1 : 0;
 }
 static int rows_multi_plan(int n, const mt_conv_desc* descs, WgradParams* ps, int* nsplit, int* rps, size_t* offs, size_t* total) {

@@ -312,20 +312,23 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       WR_FRAG(rd[3], sa, aoff[0][3], aoff[1][3]);
       WR_FRAG(rd[7], sb, boff[0][3], boff[1][3]);
       __builtin_amdgcn_sched_barrier(0);
-      WR_MMA(1, 2); WR_MMA(1, 3); WR_MMA(2, 0);
+      // (the copies' address arithmetic rides between the MFMAs from here on: every MFMA holds the matrix pipe for 16 cycles)
+      WR_MMA(1, 2);
+      issue_copy(std::integral_constant<int, 0>{});
+      WR_MMA(1, 3); WR_MMA(2, 0);
       __builtin_amdgcn_sched_barrier(0);
       WR_FRAG(rd[8], sa, aoff9[0], aoff9[1]);
       WR_FRAG(rd[9], sb9, boff9[0][0], boff9[1][0]);
       __builtin_amdgcn_sched_barrier(0);
-      WR_MMA(2, 1); WR_MMA(2, 2); WR_MMA(2, 3);
+      WR_MMA(2, 1);
+      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, 1>{});
+      WR_MMA(2, 2); WR_MMA(2, 3);
       __builtin_amdgcn_sched_barrier(0);
       WR_FRAG(rd[10], sb9, boff9[0][1], boff9[1][1]);
       __builtin_amdgcn_sched_barrier(0);
-      WR_MMA(3, 0); WR_MMA(3, 1);
-      // (from here on the scheduler may mix the copies' address arithmetic with the remaining MFMAs)
-      issue_copy(std::integral_constant<int, 0>{});
-      WR_MMA(3, 2); WR_MMA(3, 3);
-      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, 1>{});
+      WR_MMA(3, 0);
+      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, G::CPW - 1>{});
+      WR_MMA(3, 1); WR_MMA(3, 2); WR_MMA(3, 3);
 #ifndef MT_WR_EXP_NOMFMA
       acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[9], mm[8], acc9[0], 0, 0, 0);
       acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mm[10], mm[8], acc9[1], 0, 0, 0);
@@ -338,7 +341,9 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       c_bslot9 += S;
       c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
       __builtin_amdgcn_sched_barrier(0);
-      if (two_copies) issue_copy(std::integral_constant<int, G::CPW - 1>{});
+      if constexpr (G::CPW == 2) {                 // (stride 1: wave 0 alone has a second copy)
+        if (two_copies) issue_copy(std::integral_constant<int, 1>{});
+      }
       advance_load();
       __builtin_amdgcn_sched_barrier(0);
     };

@@ -959,7 +959,13 @@ def _wgrad_rows_launch(items):
     xs = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
     dys = (C.c_void_p * n)(*[it[3].data_ptr() for it in items])
     gws = (C.c_void_p * n)(*[it[4].data_ptr() for it in items])
-    with _oplog("wgrad_rows", items[0][1], (0, n)):
+    macs = 0
+    if _OPLOG["on"]:                                   # (tools/layer_table.py: the launch's work is the sum over its layers)
+        for it in items:
+            d = it[1]
+            pix = d.N * d.H * d.W if d.transposed else d.N * ((d.H + 2 * d.pad - d.kh) // d.stride + 1) * ((d.W + 2 * d.pad - d.kw) // d.stride + 1)
+            macs += pix * d.Ci * d.Co * d.kh * d.kw
+    with _oplog("wgrad_rows", items[0][1], (0, n, macs)):
         L.check(lib.mt_conv_bwd_weight_rows_multi(n, descs, xs, dys, gws, _ptr(ws), nws, 1, _stream()),
                 "mt_conv_bwd_weight_rows_multi")
     for it in items:

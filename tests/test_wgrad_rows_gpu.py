@@ -109,7 +109,7 @@ def _net_grads(ops, dev, seed, N):
         w.grad = torch.zeros_like(w)               # (accumulated into in place, as the optimizer's flat gradient buffers are)
         return w
     ws = {"down1": w_(128, 64, 3, 3), "same": w_(128, 128, 3, 3), "down2": w_(256, 128, 3, 3), "up1": w_(256, 128, 3, 3),
-          "up2": w_(128, 64, 3, 3), "s64": w_(64, 64, 3, 3)}
+          "up2": w_(128, 64, 3, 3), "s64": w_(64, 64, 3, 3), "res": w_(256, 256, 3, 3)}
     # a bias whose gradient rides on the weight-gradient call (no fused activation behind the transposed convolution)
     ws["up2_bias"] = (torch.randn(64, generator=g) * 0.1).to(dev).requires_grad_()
     ws["up2_bias"].grad = torch.zeros_like(ws["up2_bias"])
@@ -122,7 +122,9 @@ def _net_grads(ops, dev, seed, N):
         h = ops.conv2d(h, ws["same"], None, stride=1, pad=1, pad_mode="zero", act="lrelu")
         return ops.conv2d(h, ws["down2"], None, stride=2, pad=1, pad_mode="reflect")
     ha, hb = enc(xa), enc(xb)                      # every encoder weight is used twice in this backward pass
-    h = ops.conv_transpose2d(ha + hb, ws["up1"], None, stride=2, pad=1, out_pad=1, act="relu")
+    # (a 256 -> 256 layer on a 32 x 32 map: a ping-pong shape that joins the shared launches because its map is small)
+    hr = ops.conv2d(ha + hb, ws["res"], None, stride=1, pad=1, pad_mode="reflect", act="relu")
+    h = ops.conv_transpose2d(hr, ws["up1"], None, stride=2, pad=1, out_pad=1, act="relu")
     y = ops.conv_transpose2d(h, ws["up2"], ws["up2_bias"], stride=2, pad=1, out_pad=1)
     t = torch.randn(*y.shape, generator=g).to(dev)
     (y.float() * t).sum().backward()
@@ -131,7 +133,7 @@ def _net_grads(ops, dev, seed, N):
 
 
 def test_row_walker_shared_launches_match_per_layer_tile_kernels(hip_device):
-    """ten weight-gradient problems of one backward pass (six weights, four of them used twice) parked and handed over at once:
+    """eleven weight-gradient problems of one backward pass (seven weights, four of them used twice) parked and handed over at once:
     two launches of the row walker (stride 1 / stride 2 class) and one batched slab sum -- against the same pass with every
     weight gradient on the tile kernels where autograd reaches it"""
     from masterthesis_amd import _lib as L, hip_ops as ops

@@ -56,7 +56,7 @@ def main():
     for kind, d, ms in ev:
         # (a grouped weight-gradient launch carries its group size behind the descriptor: G calls of that layer)
         g = d[16] if kind == "wgrad" and len(d) > 16 else 1
-        e = agg.setdefault((kind, d[:15]), [0, 0.0])
+        e = agg.setdefault((kind, d[:15] if kind != "wgrad_rows" else d), [0, 0.0])
         e[0] += g
         e[1] += ms
     rows = []
@@ -70,6 +70,8 @@ def main():
             Ho = (f["H"] + 2 * f["pad"] - f["kh"]) // f["stride"] + 1
             Wo = (f["W"] + 2 * f["pad"] - f["kw"]) // f["stride"] + 1
             macs = f["N"] * Ho * Wo * f["Ci"] * f["Co"] * f["kh"] * f["kw"]
+        if kind == "wgrad_rows":                       # one shared launch of the row walker: d[16] layers, d[17] MACs in total
+            macs = d[17]
         flop = 2.0 * macs
         xb = f["N"] * f["H"] * f["W"] * padc(f["Ci"]) * 2
         yb = f["N"] * Ho * Wo * padc(f["Co"]) * 2
@@ -79,7 +81,10 @@ def main():
         avg = ms / n * 1e3
         name = f'{"convT" if f["transposed"] else "conv"} {f["kh"]}x{f["kw"]} s{f["stride"]} {f["Ci"]}->{f["Co"]} @{f["H"]}x{f["W"]} N{f["N"]}' \
                f'{" refl" if f["pad_mode"] else ""}'
-        rows.append((ms / a.steps, kind, name, n // a.steps, avg, flop / avg / 1e6, t_bound, t_bound / avg))
+        if kind == "wgrad_rows":
+            name = f"{d[16]} 3x3 layers of a pass, first: {name}"[:44]
+            t_bound = flop / (PEAK_TF * 1e12) * 1e6
+        rows.append((ms / a.steps, kind[:6], name, max(n // a.steps, 1), avg, flop / avg / 1e6, t_bound, t_bound / avg))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows)
     print(f"{'ms/step':>8s} {'kind':6s} {'layer':44s} {'calls':>5s} {'avg_us':>8s} {'TF/s':>7s} {'bound_us':>8s} {'frac':>5s}")
