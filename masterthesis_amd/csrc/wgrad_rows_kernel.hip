@@ -36,8 +36,8 @@
 // shared launches.  Knock-out builds (-DMT_WR_EXP_NOMFMA / NOREAD / NOCOPY / NOSLAB, tools/wgrad_rows_knockouts.sh): a tick costs
 // 0.57 us at stride 1 with everything, 0.39 without the MFMAs, 0.40 without the LDS reads, 0.56 without any memory traffic; LDS is
 // conflict-free (SQ_LDS_BANK_CONFLICT 0) and 38 % busy, the matrix pipes hold 576 of the tick's ~850 cycles: what is left is the
-// lockstep of the two waves of a SIMD around the tick's barrier (both read, then both multiply) -- the ping-pong arrangement of
-// wgrad_pipe_kernel (wave groups half a tick apart) is the next step, not taken this round.
+// lockstep of the two waves of a SIMD around the tick's barrier.  The ping-pong arrangement of wgrad_pipe_kernel (wave groups half a
+// tick apart, -DMT_WR_PINGPONG=1) was built and measured SLOWER (0.78 us per tick): a tick's memory phase is longer than its MFMAs.
 #include "conv_device.h"
 #include <stdlib.h>
 #include <string.h>
@@ -46,6 +46,11 @@
 constexpr int WR_ASLOT = 4096;              // 32 entries x 128 B
 constexpr int WR_BPLANE = 5120;             // 40 entries x 128 B (34 / 33 used)
 template <int S> struct WrGeom {
+// (1: the ping-pong form of the tick loop -- built, parity-green, and SLOWER: 0.78 us per stride-1 tick against 0.58; its memory phase
+// -- 22 reads, the copies, the waits -- is ~1.7x its 18 MFMAs, so the groups wait for each other's memory phases)
+#ifndef MT_WR_PINGPONG
+#define MT_WR_PINGPONG 0
+#endif
 #ifndef MT_WR_D1
 #define MT_WR_D1 8
 #endif
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = filter tap 0 .. 7 (+ two of the sixteen tiles of tap 8)
   const int dh = wv / 3 - 1, dwo = wv % 3;                         // tap row offset, tap column offset + 1
+  [[maybe_unused]] const int grp = wv >> 2;                         // ping-pong group (waves w and w + 4 share a SIMD)
   const int a9 = wv >> 1, fb9 = 2 * (wv & 1);                      // tap 8 (dh = 1, dwo = 2): a-fragment a9 x c-fragments fb9, fb9 + 1
 
   // ---- which problem of the launch (blocks of a problem are consecutive, blk0 a multiple of 8), which block of its dW, which
@@ -179,9 +185,11 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
   const __amdgpu_buffer_rsrc_t rsc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(ckind[G::CPW - 1] == 0 ? pa : pb), 0, ckind[G::CPW - 1] == 0 ? a_bytes : b_bytes, 0x00020000);
   // LDS starts as zeros (a ring slot that no copy has reached yet is read by the unconditional ticks), both fragment sets too
   for (int i = tid; i < G::LDS_BYTES / 16; i += 512) smem[i] = u32x4{0u, 0u, 0u, 0u};
+#if !MT_WR_PINGPONG
   bf16x8 fP[11], fQ[11];           // 0..3 a-fragments, 4..7 c-fragments of the wave's tap, 8 a-fragment + 9, 10 c-fragments of tap 8
 #pragma unroll
   for (int i = 0; i < 11; i++) { fP[i] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); fQ[i] = fP[i]; }
+#endif
   __syncthreads();
 
   for (int gpos = gbeg; gpos < gend;) {
@@ -267,6 +275,85 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
     int c_bslot9 = (S == 1 ? 0 : 1);
 
+#if MT_WR_PINGPONG
+    // PING-PONG over the two waves of a SIMD (waves w and w + 4: group = wv >> 2; the arrangement of wgrad_pipe_kernel): a tick is a
+    // memory phase (22 transposing reads of tick j, the copies of tick j + D, the waits) and a compute phase (18 MFMAs), two barriers
+    // per tick, and group 1 runs ONE BARRIER behind group 0 -- while one wave of a SIMD waits, copies and reads, the other multiplies.
+    // With everything in one phase the two waves of a SIMD read together and multiplied together: knock-outs put the matrix pipes at
+    // 0.69 busy, the rest being the barrier, the copy issue and the read latency with nothing to multiply.
+    // Ordering: a wave ends its memory phase with vmcnt((D-1) c) behind the copies of tick j + D, i.e. its copies up to tick j + 1
+    // have landed when it passes the next barrier -- group 0 reads tick j behind barrier 2 j (group 1 passed it at the end of its
+    // memory phase j - 1: tick j landed), group 1 behind barrier 2 j + 1 (group 0 passed it at the end of its memory phase j).  The
+    // dense ring slot that the copies of tick j + D refill was read for tick j - 1: retired by both groups before barrier 2 j.
+    bf16x8 fr_[11];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");       // (run start: the first D ticks; short runs are rare)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int j = 0; j < T; j++) {
+      const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
+      const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
+      const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
+#define WR_FRAG(dst, base, o0, o1)                                                                          \
+      {                                                                                                     \
+        const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                                 \
+        dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));          \
+      }
+#pragma unroll
+      for (int f = 0; f < 4; f++) WR_FRAG(fr_[f], sa, aoff[0][f], aoff[1][f]);
+      WR_FRAG(fr_[4], sb, boff[0][0], boff[1][0]);
+      WR_FRAG(fr_[5], sb, boff[0][1], boff[1][1]);
+      WR_FRAG(fr_[6], sb, boff[0][2], boff[1][2]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_copy(std::integral_constant<int, 0>{});                  // (15 reads may be outstanding: the copies' arithmetic fills the gap)
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(fr_[7], sb, boff[0][3], boff[1][3]);
+      WR_FRAG(fr_[8], sa, aoff9[0], aoff9[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (G::CPW > 2) issue_copy(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      WR_FRAG(fr_[9], sb9, boff9[0][0], boff9[1][0]);
+      WR_FRAG(fr_[10], sb9, boff9[0][1], boff9[1][1]);
+#undef WR_FRAG
+      __builtin_amdgcn_sched_barrier(0);
+      if (two_copies) issue_copy(std::integral_constant<int, G::CPW - 1>{});
+      advance_load();
+      c_aslot = c_aslot + 1 == G::NA ? 0 : c_aslot + 1;
+      c_bslot += S;
+      c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
+      c_bslot9 += S;
+      c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
+      __builtin_amdgcn_sched_barrier(0);
+      if (two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * (G::CPW - 1)) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      // gathered operand as MFMA A: a lane ends with 4 consecutive columns of one a-channel (16-byte slab stores)
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr_[4 + b], fr_[a], acc[a][b], 0, 0, 0);
+      acc9[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr_[9], fr_[8], acc9[0], 0, 0, 0);
+      acc9[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr_[10], fr_[8], acc9[1], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!grp) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     // One tick.  Knock-outs (round 4) put the first form of this loop -- barrier, copies, 22 transposing reads, wait, 18 MFMAs, one
     // after the other -- at 0.21 us of barrier + copy issue, 0.19 us of LDS reads and 0.19 us of MFMAs per tick with NO overlap
     // between them (a wave can have 15 LDS reads outstanding, so the 16th blocks the issue of everything behind it, and the copy
@@ -352,6 +439,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       tick(fQ, fP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     // the trailing (all-zero) copies must have landed, and every wave must be done with the ring, before the next run refills it
     // (or the wave exits)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
