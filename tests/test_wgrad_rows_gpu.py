@@ -161,3 +161,59 @@ def test_row_walker_shared_launches_match_per_layer_tile_kernels(hip_device):
         rel = ((g1[k] - g0[k]).norm() / g0[k].norm()).item()
         assert rel < 2e-5, f"{k}: rel L2 {rel:.3e} between the shared launches and the per-layer tile kernels"
     assert g1["up2_bias"].abs().max() > 0
+
+
+def _fuzz_cases(n=14, seed=4321):
+    import random
+    r = random.Random(seed)
+    out = []
+    for i in range(n):
+        kind = r.choice(["conv", "conv", "convT"])
+        stride = 2 if kind == "convT" else r.choice([1, 2])
+        Ci, Co = r.choice([64, 128, 192]), r.choice([64, 128])
+        if kind == "conv":
+            Wo, Ho = 32 * r.randint(1, 3), r.randint(2, 41)
+            H, W = Ho * stride, Wo * stride
+        else:
+            W, H = 32 * r.randint(1, 2), r.randint(2, 37)              # the dense operand is the INPUT of a transposed convolution
+        out.append((f"fuzz{i}", kind, r.randint(1, 5), Ci, H, W, Co, stride, r.choice(["reflect", "zero"]) if kind == "conv" else "zero"))
+    out += [("fuzzA", "conv", 3, 64, 14, 64, 128, 2, "reflect"), ("fuzzB", "conv", 2, 192, 42, 64, 64, 2, "reflect"),
+            ("fuzzC", "conv", 1, 64, 2, 32, 64, 1, "reflect")]
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}_{c[1]}_N{c[2]}_{c[3]}x{c[4]}x{c[5]}_{c[6]}_s{c[7]}_{c[8]}")
+def test_row_walker_randomised_shapes_through_the_parked_path(case, hip_device):
+    """odd map heights (two rows up), one to three strips, one to five images, 64..192 channels, every padding / stride / operand
+    role: the parked path takes every eligible shape whatever its size (runs of a few rows, runs that cross strips and images)"""
+    from masterthesis_amd import _lib as L, hip_ops as ops
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = L.load()
+    name, kind, N, Ci, H, W, Co, stride, pad_mode = case
+    g = torch.Generator().manual_seed(case_seed(name))
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    wshape = (Co, Ci, 3, 3) if kind == "conv" else (Ci, Co, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * (Ci * 9) ** -0.5).bfloat16().float()
+    prev = lib.mt_kernel_variant_enable(5, 1)
+    fused_before = ops._FUSE_WGRAD_ACC[0]
+    try:
+        ops.set_fused_grad_accumulation(True)
+        ops.set_wgrad_rows_multi(True)
+        wd = w.to(hip_device).requires_grad_()
+        wd.grad = torch.full_like(wd, 0.5)                         # (accumulated INTO: the start value must survive)
+        if kind == "conv":
+            y = ops.conv2d(x.to(hip_device), wd, None, stride=stride, pad=1, pad_mode=pad_mode)
+        else:
+            y = ops.conv_transpose2d(x.to(hip_device), wd, None, stride=stride, pad=1, out_pad=1)
+        gy = torch.randn(*y.shape, generator=g).bfloat16().float()
+        n0 = lib.mt_kernel_variant_launches(5)
+        (y.float() * gy.to(hip_device)).sum().backward()
+        torch.cuda.synchronize()
+        assert lib.mt_kernel_variant_launches(5) - n0 == 1
+        got = wd.grad.detach().float().cpu() - 0.5
+    finally:
+        ops.set_fused_grad_accumulation(fused_before)
+        lib.mt_kernel_variant_enable(5, prev)
+    ref = _reference(case, x, w, gy)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 3e-5, f"{case}: rel L2 {rel:.3e} to the fp32 CPU reference"
