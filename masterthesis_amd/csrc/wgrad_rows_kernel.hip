@@ -35,8 +35,10 @@
 // Measured (profiles/round4_wgrad_rows_*): 1.2-1.4x the tile kernel per launch, -0.75 ms of kernel time per --ms_dis step with the
 // shared launches.  Knock-out builds (-DMT_WR_EXP_NOMFMA / NOREAD / NOCOPY / NOSLAB, tools/wgrad_rows_knockouts.sh): a tick costs
 // 0.57 us at stride 1 with everything, 0.39 without the MFMAs, 0.40 without the LDS reads, 0.56 without any memory traffic; LDS is
-// conflict-free (SQ_LDS_BANK_CONFLICT 0) and 38 % busy, the matrix pipes hold 576 of the tick's ~850 cycles: what is left is the
-// lockstep of the two waves of a SIMD around the tick's barrier.  The ping-pong arrangement of wgrad_pipe_kernel (wave groups half a
+// conflict-free (SQ_LDS_BANK_CONFLICT 0) and 38 % busy, the matrix pipes hold 576 of the tick's ~850 cycles: what is left is
+// instruction ISSUE: 3.5 scalar + 3.1 vector + 1.2 LDS instructions per MFMA (SQ_INSTS_*; 144 instructions per wave and tick for 18
+// MFMAs: slot counters, the copies' row arithmetic, one address add per read) -- a wave issues one instruction per four cycles, so its
+// stream needs ~36 cycles per MFMA against 32 of the shared matrix pipe.  Next: two output rows per tick.  The ping-pong arrangement of wgrad_pipe_kernel (wave groups half a
 // tick apart, -DMT_WR_PINGPONG=1) was built and measured SLOWER (0.78 us per tick): a tick's memory phase is longer than its MFMAs.
 #include "conv_device.h"
 #include <stdlib.h>
