@@ -228,30 +228,38 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       }
     }
 
-    int l_tick = 0, l_aslot = 0, l_bslot = 0;          // the next tick to load and the ring slots it fills
-    // one copy of the next tick to load (branch-free: dense / gathered by selects -- the tick's body stays ONE basic block)
+    // loader state: the next tick to load, the ring slots it fills (BYTE offsets into LDS), the dense operand's row base and the
+    // gathered operand's first row of that tick -- advanced by additions (the tick is bound by instruction issue: every scalar counts)
+    int l_tick = 0;
+    unsigned l_a = G::A_OFF, l_b = G::B_OFF;
+    const unsigned rowa_step = (unsigned)Wo * cab_b, rowb_step = (unsigned)Wi * cbb_b;
+    unsigned rowa = (unsigned)((n * Ho + h0 - G::WARM) * Wo + w0) * cab_b;     // (meaningless while l_tick < WARM: masked)
+    const unsigned nb_base = (unsigned)(n * Hi) * rowb_step;
+    int hib = S == 1 ? h0 - 1 : 2 * (h0 - 1);
+    const unsigned t_live = (unsigned)(T - G::WARM);
     auto issue_copy = [&](auto ec) {
       constexpr int e = decltype(ec)::value;
-      const bool live = l_tick < T;
-      const int h = h0 + l_tick - G::WARM;
-      const bool oka = live && l_tick >= G::WARM;                  // (h < h1 follows from l_tick < T)
-      const unsigned basea = (unsigned)((n * Ho + h) * Wo + w0) * cab_b;
-      const int hi0 = S == 1 ? h0 - 1 + l_tick : 2 * (h0 + l_tick - 1) + crow[e];
-      int hr = hi0 < 0 ? -hi0 : hi0;
-      hr = hr >= Hi ? 2 * (Hi - 1) - hr : hr;
-      const int hi = refl ? hr : hi0;
-      const bool okb = live && (unsigned)hi < (unsigned)Hi;
-      const unsigned baseb = (unsigned)((n * Hi + hi) * Wi) * cbb_b;
-      int bs = l_bslot + crow[e];
-      bs = bs >= G::NB ? bs - G::NB : bs;
-      const bool isa = ckind[e] == 0;
-      const bool ok = isa ? oka : okb;
-      const unsigned base = isa ? basea : baseb;
-      const unsigned dst = (isa ? (unsigned)(G::A_OFF + l_aslot * WR_ASLOT) : (unsigned)(G::B_OFF + bs * G::BSLOT)) + cdst[e];
+      unsigned base, okm, dst;
+      if (ckind[e] == 0) {
+        okm = (unsigned)(l_tick - G::WARM) < t_live ? 0u : OOB;      // WARM <= l_tick < T  (h < h1 follows)
+        base = rowa;
+        dst = l_a + cdst[e];
+      } else {
+        const int hi0 = hib + crow[e];
+        int hr = hi0 < 0 ? -hi0 : hi0;
+        hr = hr >= Hi ? 2 * (Hi - 1) - hr : hr;
+        const int hi = refl ? hr : hi0;
+        okm = (l_tick < T && (unsigned)hi < (unsigned)Hi) ? 0u : OOB;
+        base = nb_base + (unsigned)hi * rowb_step;
+        unsigned bs = l_b + (unsigned)crow[e] * G::BSLOT;
+        bs = bs >= (unsigned)(G::B_OFF + G::NB * G::BSLOT) ? bs - (unsigned)(G::NB * G::BSLOT) : bs;
+        dst = bs + cdst[e];
+      }
+      // out of range if the row is (scalar mask) or the lane's pixel is (loff = OOB: the sum keeps the top bit, base < 2 GiB)
 #ifdef MT_WR_EXP_NOCOPY
-      const unsigned vo = OOB | (base & 1u) | (ok ? 2u : 0u);
+      const unsigned vo = OOB | (base & 1u) | (okm >> 30);
 #else
-      const unsigned vo = (ok && loff[e] != OOB) ? base + loff[e] : OOB;
+      const unsigned vo = (base + loff[e]) | okm;
 #endif
       if constexpr (e == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc0, (lds_ptr)(lds0 + dst), 16, vo, 0, 0, 0);
       else if constexpr (e == 1 && G::CPW > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc1, (lds_ptr)(lds0 + dst), 16, vo, 0, 0, 0);
@@ -259,9 +267,11 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     };
     auto advance_load = [&]() {
       l_tick++;
-      l_aslot = l_aslot + 1 == G::NA ? 0 : l_aslot + 1;
-      l_bslot += S;
-      l_bslot = l_bslot >= G::NB ? l_bslot - G::NB : l_bslot;
+      l_a = l_a + WR_ASLOT == (unsigned)(G::A_OFF + G::NA * WR_ASLOT) ? (unsigned)G::A_OFF : l_a + WR_ASLOT;
+      l_b += S * G::BSLOT;
+      l_b = l_b >= (unsigned)(G::B_OFF + G::NB * G::BSLOT) ? l_b - (unsigned)(G::NB * G::BSLOT) : l_b;
+      rowa += rowa_step;
+      hib += S;
     };
 #pragma unroll
     for (int s = 0; s < G::D; s++) {
@@ -271,11 +281,21 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       advance_load();
     }
 
-    // ring slot of this tap's input row at tick 0: row sequence index  S j + (S == 1 ? dh - 1 : dh)  (tap 8: dh = 1)
-    int c_aslot = 0;
-    int c_bslot = (S == 1 ? dh - 1 : dh) + G::NB;
-    c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
-    int c_bslot9 = (S == 1 ? 0 : 1);
+    // ring slots of this tap's input row (and of tap 8's: dh = 1) and of the dense segment at tick 0, as LDS byte addresses: row
+    // sequence index  S j + (S == 1 ? dh - 1 : dh)
+    const unsigned a_end = lds_base + G::A_OFF + G::NA * WR_ASLOT, b_end = lds_base + G::B_OFF + G::NB * G::BSLOT;
+    unsigned c_a = lds_base + G::A_OFF;
+    int cb0 = (S == 1 ? dh - 1 : dh) + G::NB;
+    cb0 = cb0 >= G::NB ? cb0 - G::NB : cb0;
+    unsigned c_b = lds_base + G::B_OFF + (unsigned)cb0 * G::BSLOT;
+    unsigned c_b9 = lds_base + G::B_OFF + (S == 1 ? 0u : (unsigned)G::BSLOT);
+    auto advance_compute = [&]() {
+      c_a = c_a + WR_ASLOT == a_end ? lds_base + G::A_OFF : c_a + WR_ASLOT;
+      c_b += S * G::BSLOT;
+      c_b = c_b >= b_end ? c_b - (unsigned)(G::NB * G::BSLOT) : c_b;
+      c_b9 += S * G::BSLOT;
+      c_b9 = c_b9 >= b_end ? c_b9 - (unsigned)(G::NB * G::BSLOT) : c_b9;
+    };
 
 #if MT_WR_PINGPONG
     // PING-PONG over the two waves of a SIMD (waves w and w + 4: group = wv >> 2; the arrangement of wgrad_pipe_kernel): a tick is a
@@ -298,9 +318,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       __builtin_amdgcn_sched_barrier(0);
     }
     for (int j = 0; j < T; j++) {
-      const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
-      const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
-      const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
+      const unsigned sa = c_a, sb = c_b, sb9 = c_b9;
 #define WR_FRAG(dst, base, o0, o1)                                                                          \
       {                                                                                                     \
         const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                                 \
@@ -325,11 +343,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       __builtin_amdgcn_sched_barrier(0);
       if (two_copies) issue_copy(std::integral_constant<int, G::CPW - 1>{});
       advance_load();
-      c_aslot = c_aslot + 1 == G::NA ? 0 : c_aslot + 1;
-      c_bslot += S;
-      c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
-      c_bslot9 += S;
-      c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
+      advance_compute();
       __builtin_amdgcn_sched_barrier(0);
       if (two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * (G::CPW - 1)) : "memory");
@@ -369,9 +383,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const unsigned sa = lds_base + G::A_OFF + (unsigned)c_aslot * WR_ASLOT;
-      const unsigned sb = lds_base + G::B_OFF + (unsigned)c_bslot * G::BSLOT;
-      const unsigned sb9 = lds_base + G::B_OFF + (unsigned)c_bslot9 * G::BSLOT;
+      const unsigned sa = c_a, sb = c_b, sb9 = c_b9;
 #define WR_FRAG(dst, base, o0, o1)                                                                          \
       {                                                                                                     \
         const s16x4 lo = wr_tr16<0>(base + o0), hi = wr_tr16<0>(base + o1);                                 \
@@ -424,11 +436,7 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
 #endif
 #undef WR_FRAG
 #undef WR_MMA
-      c_aslot = c_aslot + 1 == G::NA ? 0 : c_aslot + 1;
-      c_bslot += S;
-      c_bslot = c_bslot >= G::NB ? c_bslot - G::NB : c_bslot;
-      c_bslot9 += S;
-      c_bslot9 = c_bslot9 >= G::NB ? c_bslot9 - G::NB : c_bslot9;
+      advance_compute();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (G::CPW == 2) {                 // (stride 1: wave 0 alone has a second copy)
         if (two_copies) issue_copy(std::integral_constant<int, 1>{});
