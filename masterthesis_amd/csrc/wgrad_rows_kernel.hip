@@ -378,7 +378,8 @@ __global__ __launch_bounds__(512) void wgrad_rows_kernel(const WrMulti m) {
     // the last MFMAs.  Nothing is conditional: the dense operand's ring slot of a tick without an output row (warm-up, past the end)
     // holds zeros (out-of-range copies write zeros; LDS is cleared at kernel start), so its MFMAs add 0.
     auto tick = [&](bf16x8 (&rd)[11], const bf16x8 (&mm)[11]) {
-      if (two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
+      // (stride 2: every wave has CPW copies per tick -- no branch; stride 1: wave 0 alone has a second one)
+      if (G::NCOPY == 8 * G::CPW || two_copies) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * G::CPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((G::D - 1) * (G::CPW - 1)) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
